@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by running the *reference* (pyPeriod v1,
+mounted read-only at /root/reference) on seeded inputs.  Build container only: the
+reference never travels to the GPU box, the .npz files written here do.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Shims -- none of them changes reference arithmetic:
+  1. ``builtins.Any = typing.Any`` so that ``import pyPeriod`` survives QOPeriods.py:86.
+  2. the reference's own ``get_factors(n, remove_1_and_n)`` (RamanujanPeriods.py:25-39) is
+     bound into the Periods module namespace, because Periods.py:209,548 call it with that
+     keyword while Periods.py:55 defines a different signature.
+  3. QOPeriods cannot be constructed (QOPeriods.py:190); a ``class QO(QOPeriods, Periods)``
+     instance is created with ``object.__new__`` and the attribute list of QOPeriods.py:191-199.
+Only data (inputs + the reference's outputs) is stored; no reference source.
+"""
+
+import builtins
+import contextlib
+import io
+import os
+import sys
+import typing
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from pyperiod_amd.synth import multi_sinusoid_window, readme_window  # noqa: E402
+
+
+def load_reference():
+    builtins.Any = typing.Any  # shim 1
+    sys.path.insert(0, "/root/reference")
+    import pyPeriod  # noqa: F401
+
+    per_mod = sys.modules["pyPeriod.Periods"]
+    ram_mod = sys.modules["pyPeriod.RamanujanPeriods"]
+    qo_mod = sys.modules["pyPeriod.QOPeriods"]
+    per_mod.get_factors = ram_mod.get_factors  # shim 2
+    return per_mod, ram_mod, qo_mod
+
+
+def main():
+    warnings.simplefilter("ignore")
+    per_mod, ram_mod, qo_mod = load_reference()
+    Periods = per_mod.Periods
+    Ram = ram_mod.RamanujanPeriods
+    FLAGS = [(False, False), (True, False), (False, True), (True, True)]
+
+    # ---------------------------------------------------------------- KATs
+    kat = {
+        "project_arange10_p3": Periods.project(np.arange(10.0), 3),
+        "project_arange10_p3_trunc": Periods.project(np.arange(10.0), 3, True),
+        "norm_arange10": np.float64(Periods.periodic_norm(np.arange(10.0))),
+        "norm_arange10_p3": np.float64(Periods.periodic_norm(np.arange(10.0), 3)),
+        "cq6": Ram.Cq(6),
+        "phi_9_10": np.array([qo_mod.phi(9), qo_mod.phi(10)]),
+        "n_primes_10000": np.int64(len(Periods.PRIMES)),
+    }
+    # divisor-set iteration order as the reference sees it (CPython set order)
+    order_n = np.arange(2, 1400)
+    kat["factor_order_n"] = order_n
+    flat, off = [], [0]
+    for n in order_n:
+        flat += [int(v) for v in per_mod.get_factors(int(n), remove_1_and_n=True)]
+        off.append(len(flat))
+    kat["factor_order_flat"] = np.array(flat, dtype=np.int64)
+    kat["factor_order_off"] = np.array(off, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "kat.npz"), **kat)
+
+    # ---------------------------------------------------------------- project
+    out = {}
+    for n in (10, 97, 240, 4096):
+        x = multi_sinusoid_window(7, n) if n >= 64 else np.random.default_rng(n).standard_normal(n)
+        out[f"x_{n}"] = x
+        for p in (2, 3, 7, 12, 64, 97, n // 2):
+            if p > n or p < 2:
+                continue
+            for trunc, orth in FLAGS:
+                full = Periods.project(x, p, trunc, orth)
+                single = Periods.project(x, p, trunc, orth, True)
+                key = f"n{n}_p{p}_t{int(trunc)}_o{int(orth)}"
+                assert np.array_equal(full[:p], single)
+                if n <= 240:
+                    out[key] = full
+                else:
+                    # every projection is p-periodic; the first period determines it
+                    assert np.array_equal(np.tile(single, n // p + 1)[:n], full)
+                    out[key + "_single"] = single
+    np.savez_compressed(os.path.join(HERE, "project.npz"), **out)
+
+    # ---------------------------------------------------------------- sweeps (N=4096, 4 windows)
+    out = {}
+    n = 4096
+    p_lo, p_hi = 2, n // 3
+    for w in range(4):
+        x = multi_sinusoid_window(w, n)
+        plain = np.zeros(p_hi - p_lo + 1)
+        gamma = np.zeros_like(plain)
+        maxabs = np.zeros_like(plain)
+        for k, p in enumerate(range(p_lo, p_hi + 1)):
+            base = Periods.project(x, p, False, False)
+            plain[k] = Periods.periodic_norm(base)
+            gamma[k] = Periods.periodic_norm(base, p)
+            maxabs[k] = max(abs(sum(x[s::p])) for s in range(p)) if w == 0 else np.nan
+        out[f"plain_w{w}"] = plain
+        out[f"gamma_w{w}"] = gamma
+        if w == 0:
+            out["maxabs_w0"] = maxabs
+    x = multi_sinusoid_window(0, n)
+    for trunc, orth in FLAGS[1:]:
+        out[f"plain_w0_t{int(trunc)}_o{int(orth)}"] = np.array(
+            [Periods.periodic_norm(Periods.project(x, p, trunc, orth)) for p in range(p_lo, p_hi + 1)]
+        )
+    np.savez_compressed(os.path.join(HERE, "sweep.npz"), **out)
+
+    # ---------------------------------------------------------------- small_to_large
+    out = {}
+    c1 = readme_window(2000, 0)
+    per, pw, bs = Periods().small_to_large(c1, thresh=0.1)  # BASELINE config 1
+    out["c1_periods"], out["c1_powers"], out["c1_bases"] = np.array(per), np.array(pw), np.array(bs)
+    for w in range(4):
+        x = multi_sinusoid_window(w, 4096)
+        per, pw, bs = Periods().small_to_large(x, thresh=0.05)  # config 4 unit
+        out[f"w{w}_periods"], out[f"w{w}_powers"] = np.array(per), np.array(pw)
+        if w == 1:
+            out["w1_bases"] = np.array(bs)
+    for trunc, orth in FLAGS[1:]:
+        x = multi_sinusoid_window(2, 1200)
+        per, pw, bs = Periods(trunc, orth).small_to_large(x, thresh=0.05)
+        tag = f"n1200_t{int(trunc)}_o{int(orth)}"
+        out[tag + "_periods"], out[tag + "_powers"], out[tag + "_bases"] = (
+            np.array(per),
+            np.array(pw),
+            np.array(bs).reshape(len(per), 1200),
+        )
+    x = multi_sinusoid_window(3, 600)
+    per, pw, bs = Periods().small_to_large(x, thresh=0.02, n_periods=100)
+    out["n600_np100_periods"], out["n600_np100_powers"] = np.array(per), np.array(pw)
+    np.savez_compressed(os.path.join(HERE, "small_to_large.npz"), **out)
+
+    # ---------------------------------------------------------------- m_best / m_best_gamma
+    out = {}
+    for name in ("m_best", "m_best_gamma"):
+        for w in range(4):
+            x = multi_sinusoid_window(w, 4096)
+            per, pw, bs = getattr(Periods(), name)(x, num=10)  # config 2 unit
+            out[f"{name}_w{w}_periods"], out[f"{name}_w{w}_powers"] = per, pw
+            if w == 1:
+                out[f"{name}_w1_bases"] = bs
+        for w in (4, 5):
+            x = multi_sinusoid_window(w, 1500)
+            per, pw, bs = getattr(Periods(), name)(x, num=6, max_length=300, min_length=3)
+            out[f"{name}_n1500_w{w}_periods"], out[f"{name}_n1500_w{w}_powers"] = per, pw
+            out[f"{name}_n1500_w{w}_bases"] = bs
+        # README signal (config 1 shape)
+        per, pw, bs = getattr(Periods(), name)(c1, num=10)
+        out[f"{name}_c1_periods"], out[f"{name}_c1_powers"], out[f"{name}_c1_bases"] = per, pw, bs
+        # flag variants (orthogonalize *does* reach project, Periods.py:504-506)
+        for trunc, orth in FLAGS[1:]:
+            x = multi_sinusoid_window(6, 900)
+            per, pw, bs = getattr(Periods(trunc, orth), name)(x, num=5)
+            tag = f"{name}_n900_t{int(trunc)}_o{int(orth)}"
+            out[tag + "_periods"], out[tag + "_powers"], out[tag + "_bases"] = per, pw, bs
+    np.savez_compressed(os.path.join(HERE, "m_best.npz"), **out)
+
+    # ---------------------------------------------------------------- best_correlation / best_frequency
+    out = {}
+    x = multi_sinusoid_window(1, 4096)
+    per, nr, bs = Periods().best_correlation(x, num=3)
+    out["bc_n4096_periods"], out["bc_n4096_norms"], out["bc_n4096_bases"] = per, nr, bs
+    for w in (2, 3):
+        x = multi_sinusoid_window(w, 700)
+        per, nr, bs = Periods().best_correlation(x, num=5, ratio=0.01)
+        out[f"bc_n700_w{w}_periods"], out[f"bc_n700_w{w}_norms"], out[f"bc_n700_w{w}_bases"] = per, nr, bs
+    per, pw, bs = Periods().best_frequency(c1, win_size=None, num=4)
+    out["bf_c1_periods"], out["bf_c1_powers"], out["bf_c1_bases"] = per, pw, bs
+    np.savez_compressed(os.path.join(HERE, "best_correlation.npz"), **out)
+
+    # ---------------------------------------------------------------- Ramanujan
+    out = {}
+    ram = Ram()
+    for q in range(1, 65):
+        out[f"cq_{q}"] = Ram.Cq(q)
+    out["cq_complete_6_20"] = ram.Cq_complete(6, 20)
+    x = multi_sinusoid_window(0, 240)
+    out["norms_n240"] = ram.find_periods(x, 2, 80)
+    x = multi_sinusoid_window(1, 8192)
+    out["norms_n8192_pmax64"] = ram.find_periods(x, 2, 64)
+    x = multi_sinusoid_window(2, 1000)
+    out["norms_n1000_default"] = ram.find_periods(x)  # max_length = N // 3
+    np.savez_compressed(os.path.join(HERE, "ramanujan.npz"), **out)
+
+    # ---------------------------------------------------------------- QOPeriods pieces (config 5)
+    out = {}
+    QOP = qo_mod.QOPeriods
+
+    class QO(QOP, Periods):  # shim 3
+        pass
+
+    qo = object.__new__(QO)
+    qo._trunc_to_integer_multiple = False
+    qo._orthogonalize = False
+    qo._output = None
+    qo._basis_type = "natural"
+    qo._verbose = False
+    qo._k = 0
+    qo._window = False
+    qo._output_bases = None
+    qo._container = []
+    a_mat, dims = qo.get_subspaces([37, 64, 101], 16384)
+    out["dims_37_64_101_keys"] = np.array([int(k) for k in dims.keys()])
+    out["dims_37_64_101_vals"] = np.array([int(v) for v in dims.values()])
+    a_mat, dims = qo.get_subspaces([12, 18, 8, 5], 1024)
+    out["dims_12_18_8_5_vals"] = np.array([int(v) for v in dims.values()])
+    x = multi_sinusoid_window(3, 1024)
+    wts, rec = QOP.solve_quadratic(x, a_mat)
+    out["solve_x"], out["solve_w"], out["solve_recon"] = x, wts, rec
+    out["pp_5_12_keep3"] = QOP.Pp(5, 12, keep=3)
+    for tag, sig, kw in (
+        ("c1", c1, dict(num=2, thresh=0.05)),
+        ("w5", multi_sinusoid_window(5, 1536), dict(num=4, thresh=0.2, min_length=4, max_length=200)),
+    ):
+        with contextlib.redirect_stdout(io.StringIO()):  # QOPeriods.py:488 prints unconditionally
+            res_out, res = qo.find_periods(sig, **kw)
+        out[f"fp_{tag}_periods"] = np.asarray(res_out["periods"])
+        out[f"fp_{tag}_norms"] = np.asarray(res_out["norms"])
+        out[f"fp_{tag}_weights"] = np.asarray(res_out["weights"])
+        out[f"fp_{tag}_dict_keys"] = np.array([int(k) for k in res_out["basis_dictionary"].keys()])
+        out[f"fp_{tag}_dict_vals"] = np.array([int(v) for v in res_out["basis_dictionary"].values()])
+        out[f"fp_{tag}_residual"] = res
+    np.savez_compressed(os.path.join(HERE, "qoperiods.npz"), **out)
+
+    total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print(f"golden fixtures written to {HERE}: {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
