@@ -1,0 +1,176 @@
+"""Drop-in ``Periods`` (Sethares & Staley periodicity transforms) on the MI355X engine.
+
+Same constructor, method names, keyword arguments and return types as the reference class
+(pyPeriod/Periods.py:90-644); every projection, norm and sweep runs in libperiod_hip.so.
+Extension over the reference: each algorithm also accepts a ``(W, N)`` batch of independent
+windows and then returns arrays/lists with a leading window axis.
+"""
+
+from __future__ import annotations
+
+import math
+from warnings import warn
+
+import numpy as np
+
+from . import _ffi
+from ._factors import PRIMES, get_factors, get_primes  # noqa: F401  (re-exported like the reference module)
+from .engine import default_engine
+
+
+def rms(x) -> float:
+    """Root mean square (Periods.py:16-30)."""
+    return np.sqrt(np.sum(np.power(x, 2)) / len(x))
+
+
+def _as_window(data):
+    """The reference requires a 1-D ndarray: a list fails at ``data.copy()`` (AttributeError,
+    Periods.py:171) and a 2-D array at the reshape (ValueError, Periods.py:176)."""
+    data.size  # noqa: B018  -- AttributeError for non-arrays, like the reference
+    arr = np.asarray(data)
+    if arr.ndim != 1:
+        raise ValueError(f"cannot fold an array of shape {arr.shape} into periods; expected 1-D")
+    return np.ascontiguousarray(arr, dtype=np.float64)
+
+
+def _raise_status(status, what):
+    status = np.asarray(status)
+    if np.any(status == _ffi.PH_ST_NO_PERIOD):
+        # reference: max_base stays None -> TypeError at Periods.py:520/537 (project(data, None)
+        # at Periods.py:334 for best_correlation)
+        raise TypeError(f"{what}: no candidate period has a positive norm (all-zero or NaN window)")
+    if np.any(status == _ffi.PH_ST_ITER_CAP):
+        raise RuntimeError(f"{what}: iteration bound reached before `num` periods were found")
+
+
+class Periods:
+    PRIMES = PRIMES  # Periods.py:121
+
+    def __init__(self, trunc_to_integer_multiple: bool = False, orthogonalize: bool = False):
+        self._trunc_to_integer_multiple = trunc_to_integer_multiple
+        self._orthogonalize = orthogonalize
+
+    # ------------------------------------------------------------------ leaf operations
+    @staticmethod
+    def project(data, p=2, trunc_to_integer_multiple=False, orthogonalize=False, return_single_period=False):
+        """Projection onto the p-periodic subspace (Periods.py:142-219)."""
+        x = _as_window(data)
+        p = int(p)
+        if p > x.size:
+            warn("invalid value encountered in divide", RuntimeWarning)  # 0/0 columns, Periods.py:194
+        out = default_engine().project_batch(
+            x[None, :], [p], bool(trunc_to_integer_multiple), bool(orthogonalize)
+        )[0, 0]
+        if trunc_to_integer_multiple and getattr(data, "dtype", None) == np.float32:
+            out = out.astype(np.float32)  # np.mean keeps float32 (Periods.py:180-184)
+        return out[0:p] if return_single_period else out
+
+    @staticmethod
+    def periodic_norm(x, p=None):
+        """||x|| / sqrt(len(x)) [/ sqrt(p)]  (Periods.py:221-241)."""
+        arr = np.ascontiguousarray(np.asarray(x), dtype=np.float64).reshape(1, -1)
+        return np.float64(default_engine().periodic_norm(arr, p if p else None)[0])
+
+    # ------------------------------------------------------------------ algorithms
+    def _batch(self, data):
+        arr = np.asarray(data)
+        if arr.ndim == 2:
+            return np.ascontiguousarray(arr, dtype=np.float64), True
+        return _as_window(data)[None, :], False
+
+    def small_to_large(self, data, thresh: float = 0.1, n_periods: int = None):
+        """Small-to-large (Periods.py:246-287): three lists (periods, powers, bases)."""
+        x, batched = self._batch(data)
+        if n_periods is None:
+            n_periods = math.floor(x.shape[1] / 2)
+        counts, per, pw, bs, _ = default_engine().small_to_large(
+            x, thresh, n_periods, self._trunc_to_integer_multiple, self._orthogonalize
+        )
+        res = []
+        for w in range(x.shape[0]):
+            k = int(counts[w])
+            res.append(
+                ([int(v) for v in per[w, :k]], [np.float64(v) for v in pw[w, :k]], [bs[w, i].copy() for i in range(k)])
+            )
+        return res if batched else res[0]
+
+    def best_correlation(self, data, num: int = 5, max_length: int = None, ratio: float = 0.01):
+        """Best-correlation (Periods.py:289-349)."""
+        x, batched = self._batch(data)
+        if max_length is None:
+            max_length = math.floor(x.shape[1] / 3)
+        per, nr, bs, st = default_engine().best_correlation(
+            x, num, max_length, ratio, self._trunc_to_integer_multiple, self._orthogonalize
+        )
+        _raise_status(st, "best_correlation")
+        return (per, nr, bs) if batched else (per[0], nr[0], bs[0])
+
+    def best_frequency(self, data, win_size: int = None, num: int = 5):
+        """Best-frequency (Periods.py:351-398): the spectral peak is picked with numpy's
+        rfft on the host (as in the reference); every projection and norm runs on the GPU."""
+        x = _as_window(data)
+        if win_size is None:
+            win_size = len(x)
+        elif win_size < len(x):
+            warn("win_size is smaller than the input signal length. It will be truncated and information will be lost.")
+        eng = default_engine()
+        periods = np.zeros(num, dtype=np.uint32)
+        norms = np.zeros(num)
+        bases = np.zeros((num, len(x)))
+        work = x.copy()
+        for i in range(num):
+            mags = np.abs(np.fft.rfft(work, win_size))
+            p = int(np.round((2 * win_size) / np.argmax(mags)))
+            base = eng.project_batch(work[None, :], [p], self._trunc_to_integer_multiple, self._orthogonalize)[0, 0]
+            periods[i] = p
+            norms[i] = eng.periodic_norm(base[None, :])[0]
+            bases[i] = base
+            work = work - base
+        return (periods, norms / eng.periodic_norm(x[None, :])[0], bases)
+
+    def m_best(self, data, num: int = 5, max_length: int = None, min_length: int = 2):
+        """M-best (Periods.py:408-430)."""
+        return self._m_best_meta(data, None, num, max_length, min_length)
+
+    def m_best_gamma(self, data, num: int = 5, max_length: int = None, min_length: int = 2):
+        """M-best gamma (Periods.py:432-454)."""
+        return self._m_best_meta(data, "gamma", num, max_length, min_length)
+
+    def _m_best_meta(self, data, type, num=5, max_length=None, min_length=2):
+        """Periods.py:456-601: both steps run on the device (one launch pair per batch)."""
+        if self.orthogonalize:
+            warn("`Orthogonalize = True` has no effect in M-best.")  # Periods.py:482-483
+        x, batched = self._batch(data)
+        if max_length is None:
+            max_length = math.floor(x.shape[1] / 3)
+        per, pw, bs, st = default_engine().m_best(
+            x, num, max_length, min_length, type is not None, self._trunc_to_integer_multiple, self._orthogonalize
+        )
+        _raise_status(st, "m_best")
+        return (per, pw, bs) if batched else (per[0], pw[0], bs[0])
+
+    # ------------------------------------------------------------------ properties (Periods.py:606-644)
+    @property
+    def trunc_to_integer_multiple(self):
+        # the reference getter returns BOTH flags as a tuple (Periods.py:610-611)
+        return self._trunc_to_integer_multiple, self._orthogonalize
+
+    @trunc_to_integer_multiple.setter
+    def trunc_to_integer_multiple(self, value):
+        self._trunc_to_integer_multiple, self._orthogonalize = value
+
+    @property
+    def orthogonalize(self):
+        return self._orthogonalize
+
+    @orthogonalize.setter
+    def orthogonalize(self, value):
+        self._orthogonalize = value
+
+    @property
+    def window(self):
+        return self._window  # never set by __init__, like the reference (Periods.py:138-140)
+
+    @window.setter
+    def window(self, value):
+        self._window = value

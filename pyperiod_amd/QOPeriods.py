@@ -1,0 +1,345 @@
+"""Drop-in ``QOPeriods`` (quadratic-optimisation period finder) on the MI355X engine.
+
+Mirrors the reference surface (pyPeriod/QOPeriods.py:148-1310).  The v1 reference class cannot
+even be constructed (QOPeriods.py:190) and only its non-orthogonal ``find_periods`` branch runs
+(SURVEY.md section 0); that branch is what is implemented here, with the heavy pieces on the GPU:
+
+  * the gamma-normalised all-p sweep over the residual      -> ph_sweep          (QOPeriods.py:470-478)
+  * W = A x and A' = A A^T for natural-basis rows            -> ph_fold_sums      (QOPeriods.py:781-782)
+  * reconstruction A^T w                                     -> ph_tile_sum       (QOPeriods.py:795)
+  * the small dense solve A' w = W stays on host LAPACK, as in the reference (QOPeriods.py:794).
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import _ffi
+from ._factors import PRIMES, get_factors, get_primes, phi  # noqa: F401
+from .engine import default_engine
+from .Periods import Periods, _as_window, rms
+
+
+def flatten(t: list) -> list:
+    return [item for sublist in t for item in sublist]
+
+
+def normalize(x, level: int = 1):
+    """Scale so that max |x| == level (QOPeriods.py:119-145)."""
+    x = np.asarray(x)
+    return (x / np.max(np.abs(x))) * level
+
+
+def ramanujan_sum(q: int) -> np.ndarray:
+    """c_q(n) for n < q as exact integers: c_q(n) = sum_{d | gcd(n,q)} mu(q/d) d.  The reference
+    evaluates the same numbers through complex exponentials (QOPeriods.py:1035-1044) and carries
+    ~1e-12 of rounding noise on top of these integers."""
+    q = int(q)
+    mu = np.ones(q + 1, dtype=np.int64)
+    is_comp = np.zeros(q + 1, dtype=bool)
+    for i in range(2, q + 1):
+        if not is_comp[i]:
+            is_comp[2 * i :: i] = True
+            mu[i::i] *= -1
+            mu[i * i :: i * i] = 0
+    n = np.arange(q)
+    g = np.gcd(n, q)
+    out = np.zeros(q, dtype=np.int64)
+    for d in range(1, q + 1):
+        if q % d == 0 and mu[q // d] != 0:
+            out[g % d == 0] += mu[q // d] * d
+    return out
+
+
+class QOPeriods(Periods):
+    PRIMES = PRIMES  # QOPeriods.py:149-151
+
+    def __init__(self, basis_type="natural", trunc_to_integer_multiple=False, orthogonalize=False):
+        super().__init__(trunc_to_integer_multiple, orthogonalize)
+        # attribute list of QOPeriods.py:191-199
+        self._output = None
+        self._basis_type = basis_type
+        self._verbose = False
+        self._k = 0
+        self._window = False
+        self._output_bases = None
+        self._container = []
+
+    # ------------------------------------------------------------------ detection
+    def find_periods(self, data, num=None, thresh=None, min_length=2, max_length=None, update_weights=True, **kwargs):
+        """Greedy period selection with re-solved weights (QOPeriods.py:313-596).
+        Returns ``(dict(periods, norms, subspaces, weights, basis_dictionary), residual)``."""
+        data = _as_window(data)
+        N = len(data)
+        if max_length is None:
+            max_length = int(np.floor(N / 3))
+        if num is None:
+            num = N
+        periods = np.zeros(num, dtype=np.uint32)
+        norms = np.zeros(num)
+        res = data.copy()
+        output_weights = np.array([])
+        basis_matricies = np.empty((0, N))
+        basis_dictionary = {}
+        if "test_function" in kwargs:
+            test_function = kwargs["test_function"]
+        else:
+            test_function = lambda self, x, y: rms(y) > (rms(data) * thresh)  # noqa: E731  QOPeriods.py:391
+
+        if np.sum(np.abs(data)) <= 1e-16:  # QOPeriods.py:394-406
+            output_bases = {
+                "periods": np.array([1]),
+                "norms": np.array([0]),
+                "subspaces": np.ones((1, N)),
+                "weights": np.array([0]),
+                "basis_dictionary": {"1": N},
+            }
+            self._output = output_bases
+            return (output_bases, np.zeros(N))
+        output_bases = {"periods": [], "norms": [], "subspaces": [], "weights": [], "basis_dictionary": {}}
+
+        if self._orthogonalize:
+            # QOPeriods.py:429-467: in the v1 reference this branch dies with TypeError
+            # (best_base is never assigned).  Row f-3 of SURVEY.md section 8: not built yet.
+            raise NotImplementedError(
+                "QOPeriods.find_periods(orthogonalize=True) is not implemented; the v1 reference "
+                "raises TypeError on this branch"
+            )
+
+        eng = default_engine()
+        reconstruction = None
+        nonzero_periods = periods[:0]
+        for i in range(num):
+            if i == 0 or test_function(self, data, reconstruction):
+                # strongest gamma-normalised projection of the residual (QOPeriods.py:470-478)
+                sweep = eng.sweep(
+                    res[None, :], min_length, max_length, _ffi.PH_SWEEP_NORM_GAMMA, self._trunc_to_integer_multiple, False
+                )[0]
+                vals = np.where(np.isnan(sweep), -np.inf, sweep)
+                k = int(np.argmax(vals))  # first maximum == strict '>' scan
+                best_p, best_norm = (min_length + k, sweep[k]) if vals[k] > 0 else (0, 0)
+                periods[i] = best_p
+                norms[i] = best_norm
+                if self._verbose:
+                    print(f"New period: {best_p}")
+                nonzero_periods = periods[periods > 0]
+                try:
+                    if update_weights:
+                        basis_matricies, basis_dictionary, output_weights, reconstruction = self._update_weights(
+                            data, N, nonzero_periods
+                        )
+                        res = data - reconstruction
+                    else:
+                        basis_matricies, basis_dictionary, output_weights, reconstruction = self._dont_update_weights(
+                            res, N, nonzero_periods, output_weights, basis_matricies, basis_dictionary
+                        )
+                        res = res - reconstruction
+                    output_bases = {
+                        "periods": nonzero_periods,
+                        "norms": norms[: len(nonzero_periods)],
+                        "subspaces": basis_matricies,
+                        "weights": output_weights,
+                        "basis_dictionary": basis_dictionary,
+                    }
+                    self._output_bases = output_bases
+                except np.linalg.LinAlgError:  # QOPeriods.py:552-559
+                    break
+            else:  # QOPeriods.py:560-594
+                if update_weights:
+                    basis_matricies, basis_dictionary, output_weights, reconstruction = self._update_weights(
+                        data, N, nonzero_periods
+                    )
+                else:
+                    basis_matricies, basis_dictionary, output_weights, reconstruction = self._dont_update_weights(
+                        res, N, nonzero_periods, output_weights, basis_matricies, basis_dictionary
+                    )
+                output_bases = {
+                    "periods": nonzero_periods[:-1],
+                    "norms": norms[: len(nonzero_periods) - 1],
+                    "subspaces": basis_matricies,
+                    "weights": output_weights,
+                    "basis_dictionary": basis_dictionary,
+                }
+                self._output_bases = output_bases
+                break
+        return (output_bases, res)
+
+    def _solve_structured(self, x, basis_matrix, dictionary):
+        """solve_quadratic for a natural-basis dictionary without touching the dense matrix
+        on the compute side: W = A x and A A^T are folds, A^T w is a tile-sum."""
+        if self._basis_type != "natural":
+            return self.solve_quadratic(x, basis_matrix, window=self.window)
+        eng = default_engine()
+        p_list = [int(q) for q in dictionary.keys()]
+        keep = [int(v) for v in dictionary.values()]
+        win = self.window
+        if win is None or win is False:
+            rhs = eng.fold_sums(x[None, :], p_list, keep)[0]
+            gram = eng.fold_sums(basis_matrix, p_list, keep)  # row (q,j) folded by p == (A A^T)^T
+        else:
+            rhs = eng.fold_sums((x * win)[None, :], p_list, keep)[0]
+            gram = eng.fold_sums(basis_matrix * win, p_list, keep)
+        weights = np.linalg.solve(gram.T, rhs)  # QOPeriods.py:794 (raises LinAlgError when singular)
+        recon = eng.tile_sum(weights[None, :], x.size, p_list, keep)[0]
+        return weights, recon
+
+    def _update_weights(self, data, N, nonzero_periods):
+        """QOPeriods.py:598-643."""
+        basis_matricies, basis_dictionary = self.get_subspaces(nonzero_periods, N)
+        output_weights, reconstruction = self._solve_structured(data, basis_matricies, basis_dictionary)
+        return (basis_matricies, basis_dictionary, output_weights, reconstruction)
+
+    def _dont_update_weights(self, data, N, nonzero_periods, output_weights, basis_matricies, basis_dictionary):
+        """QOPeriods.py:645-714 (the v1 reference overflows here under numpy 2: uint32 periods
+        reach Pp_column; periods are converted to int first)."""
+        last = int(nonzero_periods[-1])
+        keep = last
+        factors = get_factors(last)
+        existing = set()
+        for p in nonzero_periods[:-1]:
+            existing = existing.union(get_factors(int(p)))
+        for f in sorted(existing.intersection(factors)):
+            keep -= phi(f)
+        basis_matrix = self.Pp(last, N, keep=keep, type=self._basis_type)
+        weights, reconstruction = self._solve_structured(data, basis_matrix, {str(last): basis_matrix.shape[0]})
+        basis_dictionary.update({str(last): keep})
+        basis_matricies = np.vstack((basis_matricies, basis_matrix))
+        output_weights = np.concatenate((output_weights, weights))
+        return (basis_matricies, basis_dictionary, output_weights, reconstruction)
+
+    # ------------------------------------------------------------------ linear algebra
+    @staticmethod
+    def solve_quadratic(x, A, type: str = "solve", window=None, k: int = 0):
+        """Generic dense form (QOPeriods.py:743-805): A' = A A^T, W = A x, solve, A^T w.
+        The two dense products are plain library GEMMs and run through rocBLAS
+        (torch.matmul on the GPU); the small solve uses host LAPACK like the reference."""
+        import torch
+
+        eng = default_engine()
+        dev = torch.device("cuda", eng.device)
+        At = torch.as_tensor(np.ascontiguousarray(A, dtype=np.float64), device=dev)
+        xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
+        Aw = At if (window is None or window is False) else At * torch.as_tensor(np.asarray(window, dtype=np.float64), device=dev)
+        A_prime = (Aw @ At.T).cpu().numpy()
+        W = (Aw @ xt).cpu().numpy()
+        if type == "solve":
+            output = np.linalg.solve(A_prime, W)
+        else:
+            if type != "lstsq":
+                warnings.warn("type ({}) unrecognized. Defaulting to lstsq.".format(type))
+            output = np.linalg.lstsq(A_prime, W, rcond=None)[0]
+        reconstructed = (At.T @ torch.as_tensor(output, device=dev)).cpu().numpy()
+        return (output, reconstructed)
+
+    def get_subspaces(self, Q, N: int):
+        """Stacked natural-basis rows and the {period: rows kept} dictionary
+        (QOPeriods.py:807-852)."""
+        old_dimensionality = 0
+        d = {}
+        R = set()
+        for q in Q:
+            R = R.union(get_factors(int(q)))
+            s = int(np.sum([phi(r) for r in R]))
+            d[str(q)] = s - old_dimensionality
+            old_dimensionality = s
+        blocks = [self.Pp(int(q), N, keep, self._basis_type) for q, keep in d.items()]
+        A = np.vstack(blocks) if blocks else np.array([]).reshape((0, N))
+        return (A, d)
+
+    def compute_reconstruction(self, x, periods, type: str = "lstsq", window=None):
+        """QOPeriods.py:1054-1116."""
+        basis_matricies, basis_dictionary = self.get_subspaces(periods, len(x))
+        try:
+            output_weights, reconstruction = self.solve_quadratic(x, basis_matricies, window=window, type=type)
+        except np.linalg.LinAlgError:
+            return None
+        output_bases = {
+            "periods": periods,
+            "subspaces": basis_matricies,
+            "weights": output_weights,
+            "basis_dictionary": basis_dictionary,
+        }
+        return (reconstruction, output_bases)
+
+    def get_periods(self, weights, dictionary, decomp_type="row reduction"):
+        """QOPeriods.py:719-741 -- raises TypeError in the v1 reference (positional `_k` lands
+        in `type`); out of the hot-path scope."""
+        raise NotImplementedError("QOPeriods.get_periods is outside the accelerated path (broken in reference v1)")
+
+    @staticmethod
+    def concatenate_periods(weights, dictionary):
+        """QOPeriods.py:854-887."""
+        read_idx = 0
+        output = []
+        for q, r in dictionary.items():
+            v = np.zeros(int(q))
+            v[0:r] = weights[read_idx : read_idx + r]
+            read_idx += r
+            output.append(v)
+        return np.array(flatten(output))
+
+    # ------------------------------------------------------------------ dictionaries (host tables)
+    @staticmethod
+    def Pp(p: int, N: int = 1, keep: int = None, type: str = "natural") -> np.ndarray:
+        """Natural (indicator) or Ramanujan basis rows (QOPeriods.py:940-974)."""
+        p, N = int(p), int(N)
+        if type == "natural":
+            matrix = (np.arange(N)[None, :] % p == np.arange(p)[:, None]).astype(np.float64)
+        elif type == "ramanujan":
+            reps = int(np.ceil(N / p))
+            matrix = np.stack([QOPeriods.Cq(p, i, reps, "real")[:N] for i in range(p)])
+        else:
+            matrix = np.zeros((p, N))
+        return matrix[:keep] if keep else matrix
+
+    @staticmethod
+    def Pp_column(p: int, s: int, repetitions: int = 1):
+        """[.., 1 at (index - s) % p == 0, ..] tiled (QOPeriods.py:976-1003)."""
+        p, s = int(p), int(s)
+        vec = ((np.arange(p) - s) % p == 0).astype(np.float64)
+        return np.tile(vec, repetitions)
+
+    @staticmethod
+    def Cq(q: int, s: int = 0, repetitions: int = 1, type: str = "real"):
+        """Ramanujan sum c_q rolled by s and tiled (QOPeriods.py:1005-1052)."""
+        vec = np.tile(np.roll(ramanujan_sum(q).astype(np.float64), s), repetitions)
+        return vec.astype(complex) if type == "complex" else vec
+
+    # ------------------------------------------------------------------ properties (QOPeriods.py:1237-1310)
+    @property
+    def basis_type(self):
+        return self._basis_type
+
+    @basis_type.setter
+    def basis_type(self, value):
+        self._basis_type = value
+
+    @property
+    def verbose(self):
+        return self._verbose
+
+    @verbose.setter
+    def verbose(self, value):
+        self._verbose = value
+
+    @property
+    def k(self):
+        return self._k
+
+    @k.setter
+    def k(self, value):
+        self._k = value
+
+    @property
+    def window(self):
+        return self._window
+
+    @window.setter
+    def window(self, value):
+        self._window = value
+
+    @property
+    def output_bases(self):
+        return self._output_bases

@@ -1,0 +1,770 @@
+// libperiod_hip.so -- C ABI (include/periodhip.h) over the gfx950 kernels in ph_kernels.h.
+// Host side only: argument checks, device staging for host-pointer calls, small integer
+// tables, launch geometry.  No compute happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/periodhip.h"
+#include "ph_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define PH_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(e_ == hipErrorOutOfMemory ? PH_E_NOMEM : PH_E_HIP, "%s failed: %s", #call, \
+                  hipGetErrorString(e_));                                                    \
+  } while (0)
+
+#define PH_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != PH_OK) return rc_; \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct TableSlot {
+  DevBuf dev;
+  std::vector<int32_t> host;  // last uploaded content (skip identical re-uploads)
+  bool valid = false;
+};
+
+enum { T_PLIST, T_ORTH_OFF, T_ORTH_Q, T_FAC_OFF, T_FAC_Q, T_AUX0, T_AUX1, T_AUX2, T_AUX3, T_COUNT };
+enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_COUNT };
+
+}  // namespace
+
+struct ph_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 0;
+  int lds_limit = 0;
+  DevBuf buf[B_COUNT];
+  TableSlot tab[T_COUNT];
+};
+
+namespace {
+
+int ensure(ph_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return PH_OK;
+  if (b.p) {
+    PH_HIP(hipStreamSynchronize(c->stream));
+    PH_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t want = std::max<size_t>(bytes, 256);
+  PH_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  return PH_OK;
+}
+
+// Upload a small int table (host pointer) into a cached device slot.
+int upload_table(ph_ctx* c, int slot, const int32_t* src, size_t n, const int** dev_out) {
+  TableSlot& t = c->tab[slot];
+  if (n == 0) {
+    PH_TRY(ensure(c, t.dev, 16));
+    *dev_out = static_cast<const int*>(t.dev.p);
+    return PH_OK;
+  }
+  if (t.valid && t.host.size() == n && std::memcmp(t.host.data(), src, n * sizeof(int32_t)) == 0) {
+    *dev_out = static_cast<const int*>(t.dev.p);
+    return PH_OK;
+  }
+  t.valid = false;
+  // the previous content may still be in use by queued kernels
+  PH_HIP(hipStreamSynchronize(c->stream));
+  PH_TRY(ensure(c, t.dev, n * sizeof(int32_t)));
+  t.host.assign(src, src + n);
+  PH_HIP(hipMemcpyAsync(t.dev.p, t.host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  PH_HIP(hipStreamSynchronize(c->stream));
+  t.valid = true;
+  *dev_out = static_cast<const int*>(t.dev.p);
+  return PH_OK;
+}
+
+size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
+
+int check_common(ph_ctx* c, const void* x, int dtype, int64_t W, int N) {
+  if (!c) return fail(PH_E_ARG, "ctx is NULL");
+  if (!x) return fail(PH_E_ARG, "x is NULL");
+  if (dtype != PH_F64 && dtype != PH_F32) return fail(PH_E_ARG, "dtype must be PH_F64 or PH_F32");
+  if (W < 1 || W > 0x7fffffffLL / 64) return fail(PH_E_ARG, "W=%lld out of range", (long long)W);
+  if (N < 1) return fail(PH_E_ARG, "N=%d must be >= 1", N);
+  return PH_OK;
+}
+
+int check_lds(ph_ctx* c, size_t bytes, int N, const char* what) {
+  if (bytes > (size_t)c->lds_limit)
+    return fail(PH_E_ARG, "%s: window of N=%d needs %zu B of LDS, device limit is %d B", what, N, bytes,
+                c->lds_limit);
+  return PH_OK;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(PH_E_HIP, "hipFuncSetAttribute(LDS=%zu): %s", bytes, hipGetErrorString(e));
+  }
+  return PH_OK;
+}
+
+int launch_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PH_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return PH_OK;
+}
+
+// Orth tables (only when PH_FLAG_ORTH) and validation of their content.
+int prepare_orth(ph_ctx* c, unsigned flags, const int32_t* off, const int32_t* q, int table_max_p, int need_p,
+                 ph::Tables* tb) {
+  tb->orth_off = tb->orth_q = nullptr;
+  if (!(flags & PH_FLAG_ORTH)) return PH_OK;
+  if (!off || !q) return fail(PH_E_ARG, "PH_FLAG_ORTH needs orth_off/orth_q tables");
+  if (table_max_p < need_p) return fail(PH_E_ARG, "orth tables cover p <= %d, need %d", table_max_p, need_p);
+  const size_t n_off = (size_t)table_max_p + 2;
+  if (off[0] != 0) return fail(PH_E_ARG, "orth_off[0] must be 0");
+  for (size_t i = 0; i + 1 < n_off; ++i)
+    if (off[i + 1] < off[i]) return fail(PH_E_ARG, "orth_off not monotone at %zu", i);
+  const size_t n_q = (size_t)off[n_off - 1];
+  for (size_t i = 0; i < n_q; ++i)
+    if (q[i] < 1) return fail(PH_E_ARG, "orth_q[%zu]=%d must be >= 1", i, q[i]);
+  PH_TRY(upload_table(c, T_ORTH_OFF, off, n_off, &tb->orth_off));
+  PH_TRY(upload_table(c, T_ORTH_Q, q, n_q, &tb->orth_q));
+  return PH_OK;
+}
+
+int prepare_fac(ph_ctx* c, const int32_t* off, const int32_t* q, int table_max_p, int need_p, ph::Tables* tb) {
+  if (!off || !q) return fail(PH_E_ARG, "fac_off/fac_q tables are required");
+  if (table_max_p < need_p) return fail(PH_E_ARG, "factor tables cover p <= %d, need %d", table_max_p, need_p);
+  const size_t n_off = (size_t)table_max_p + 2;
+  if (off[0] != 0) return fail(PH_E_ARG, "fac_off[0] must be 0");
+  for (size_t i = 0; i + 1 < n_off; ++i)
+    if (off[i + 1] < off[i]) return fail(PH_E_ARG, "fac_off not monotone at %zu", i);
+  const size_t n_q = (size_t)off[n_off - 1];
+  for (size_t i = 0; i < n_q; ++i)
+    if (q[i] < 1 || q[i] > table_max_p) return fail(PH_E_ARG, "fac_q[%zu]=%d out of range", i, q[i]);
+  PH_TRY(upload_table(c, T_FAC_OFF, off, n_off, &tb->fac_off));
+  PH_TRY(upload_table(c, T_FAC_Q, q, n_q, &tb->fac_q));
+  return PH_OK;
+}
+
+// Host-pointer staging: `Stage` maps each user array to the pointer the kernel uses.
+struct Stage {
+  ph_ctx* c;
+  bool device;
+  struct Out {
+    void* user;
+    void* dev;
+    size_t bytes;
+  };
+  std::vector<Out> outs;
+  Stage(ph_ctx* ctx, unsigned flags) : c(ctx), device(flags & PH_FLAG_DEVICE) {}
+  int in(const void* user, size_t bytes, const void** dev) {
+    if (device) {
+      *dev = user;
+      return PH_OK;
+    }
+    PH_TRY(ensure(c, c->buf[B_IN], bytes));
+    PH_HIP(hipMemcpyAsync(c->buf[B_IN].p, user, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = c->buf[B_IN].p;
+    return PH_OK;
+  }
+  int out(int slot, void* user, size_t bytes, void** dev) {
+    if (!user) {
+      *dev = nullptr;
+      return PH_OK;
+    }
+    if (device) {
+      *dev = user;
+      return PH_OK;
+    }
+    PH_TRY(ensure(c, c->buf[slot], bytes));
+    *dev = c->buf[slot].p;
+    outs.push_back({user, *dev, bytes});
+    return PH_OK;
+  }
+  int finish() {
+    if (device) return PH_OK;
+    for (const Out& o : outs)
+      PH_HIP(hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+    PH_HIP(hipStreamSynchronize(c->stream));
+    return PH_OK;
+  }
+};
+
+int pick_chunks(ph_ctx* c, int64_t W, int items, int min_items_per_chunk) {
+  const int64_t target = (int64_t)c->num_cu * 8;  // >= 8 workgroups per CU in flight/queued
+  int64_t chunks = (target + W - 1) / W;
+  const int64_t max_chunks = std::max(1, items / std::max(1, min_items_per_chunk));
+  chunks = std::max<int64_t>(1, std::min(chunks, max_chunks));
+  return (int)chunks;
+}
+
+using ph::carve_bytes;
+using ph::kBlock;
+using ph::kMaxWaves;
+using ph::kRedDoubles;
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+int ph_version(void) { return PH_VERSION; }
+
+const char* ph_last_error(void) { return g_err.c_str(); }
+
+int ph_device_count(int* count) {
+  if (!count) return fail(PH_E_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(PH_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return PH_OK;
+}
+
+int ph_create(int device, ph_ctx** out) {
+  if (!out) return fail(PH_E_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  PH_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(PH_E_ARG, "device %d not in [0, %d)", device, n);
+  PH_HIP(hipSetDevice(device));
+  ph_ctx* c = new (std::nothrow) ph_ctx();
+  if (!c) return fail(PH_E_NOMEM, "out of host memory");
+  c->device = device;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(PH_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  }
+  c->num_cu = prop.multiProcessorCount;
+  // gfx950 has 160 KiB of LDS per CU and one workgroup may use all of it; take the largest
+  // figure the runtime reports (an oversize launch fails cleanly with a launch error).
+  size_t lds = prop.sharedMemPerBlock;
+  lds = std::max(lds, prop.sharedMemPerBlockOptin);
+  lds = std::max(lds, prop.maxSharedMemoryPerMultiProcessor);
+  c->lds_limit = (int)std::min<size_t>(lds, 160 * 1024);
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+    delete c;
+    return fail(PH_E_HIP, "stream/event creation: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return PH_OK;
+}
+
+int ph_destroy(ph_ctx* c) {
+  if (!c) return PH_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf& b : c->buf)
+    if (b.p) (void)hipFree(b.p);
+  for (TableSlot& t : c->tab)
+    if (t.dev.p) (void)hipFree(t.dev.p);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return PH_OK;
+}
+
+int ph_set_stream(ph_ctx* c, void* hip_stream) {
+  if (!c) return fail(PH_E_ARG, "ctx is NULL");
+  PH_HIP(hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return PH_OK;
+}
+
+int ph_sync(ph_ctx* c) {
+  if (!c) return fail(PH_E_ARG, "ctx is NULL");
+  PH_HIP(hipStreamSynchronize(c->stream));
+  return PH_OK;
+}
+
+int ph_timer_begin(ph_ctx* c) {
+  if (!c) return fail(PH_E_ARG, "ctx is NULL");
+  PH_HIP(hipEventRecord(c->ev0, c->stream));
+  return PH_OK;
+}
+
+int ph_timer_end(ph_ctx* c, float* ms) {
+  if (!c || !ms) return fail(PH_E_ARG, "NULL argument");
+  PH_HIP(hipEventRecord(c->ev1, c->stream));
+  PH_HIP(hipEventSynchronize(c->ev1));
+  PH_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return PH_OK;
+}
+
+int ph_device_info(ph_ctx* c, int* num_cu, int* lds_bytes) {
+  if (!c) return fail(PH_E_ARG, "ctx is NULL");
+  if (num_cu) *num_cu = c->num_cu;
+  if (lds_bytes) *lds_bytes = c->lds_limit;
+  return PH_OK;
+}
+
+int ph_max_window(ph_ctx* c, int dtype, unsigned flags, int* max_n) {
+  if (!c || !max_n) return fail(PH_E_ARG, "NULL argument");
+  const size_t sz = elem_size(dtype);
+  const size_t overhead = 8192;  // reduction scratch, bookkeeping arrays
+  const size_t bufs = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) ? 2 : 1;
+  *max_n = (int)(((size_t)c->lds_limit - overhead) / (sz * bufs));
+  return PH_OK;
+}
+
+// ----------------------------------------------------------------------------- K1
+int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, const int32_t* p_list, int n_p,
+                     const int32_t* orth_off, const int32_t* orth_q, int table_max_p, unsigned flags,
+                     void* out) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!p_list || n_p < 1 || !out) return fail(PH_E_ARG, "p_list/out NULL or n_p < 1");
+  int pmax = 1;
+  for (int k = 0; k < n_p; ++k) {
+    if (p_list[k] < 1) return fail(PH_E_ARG, "p_list[%d]=%d must be >= 1", k, p_list[k]);
+    pmax = std::max(pmax, p_list[k]);
+  }
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  size_t lds = carve_bytes(N, sz);
+  if (flags & PH_FLAG_ORTH) lds += carve_bytes(N, sz);
+  PH_TRY(check_lds(c, lds, N, "ph_project_batch"));
+  ph::Tables tb{};
+  PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, pmax, &tb));
+  const int* d_plist;
+  PH_TRY(upload_table(c, T_PLIST, p_list, n_p, &d_plist));
+  Stage st(c, flags);
+  const void* dx;
+  void* dout;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, out, (size_t)W * n_p * N * sz, &dout));
+  const int chunks = pick_chunks(c, W, n_p, 1);
+  const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH | PH_FLAG_SINGLE);
+  if (flags & PH_FLAG_SINGLE) PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * n_p * N * sz, c->stream));
+  const dim3 grid((unsigned)(W * chunks));
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_project_batch<double>, lds));
+    hipLaunchKernelGGL(ph::k_project_batch<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
+                       d_plist, n_p, chunks, kflags, tb, (double*)dout);
+  } else {
+    PH_TRY(allow_lds(ph::k_project_batch<float>, lds));
+    hipLaunchKernelGGL(ph::k_project_batch<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
+                       d_plist, n_p, chunks, kflags, tb, (float*)dout);
+  }
+  PH_TRY(launch_check("k_project_batch"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- K2
+int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, int p_hi, int mode,
+             const int32_t* orth_off, const int32_t* orth_q, int table_max_p, unsigned flags, double* out) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!out) return fail(PH_E_ARG, "out is NULL");
+  if (p_lo < 1 || p_hi < p_lo) return fail(PH_E_ARG, "need 1 <= p_lo <= p_hi (got %d, %d)", p_lo, p_hi);
+  if (mode < 0 || mode > 2) return fail(PH_E_ARG, "mode %d unknown", mode);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const bool general = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) && mode != PH_SWEEP_MAXABS;
+  size_t lds = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_sweep"));
+  ph::Tables tb{};
+  PH_TRY(prepare_orth(c, general ? flags : 0u, orth_off, orth_q, table_max_p, p_hi, &tb));
+  const int P = p_hi - p_lo + 1;
+  Stage st(c, flags);
+  const void* dx;
+  void* dout;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, out, (size_t)W * P * sizeof(double), &dout));
+  const int chunks = pick_chunks(c, W, P, 4 * (kBlock / 64));
+  const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  const dim3 grid((unsigned)(W * chunks));
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_sweep<double>, lds));
+    hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, p_lo,
+                       p_hi, mode, chunks, kflags, tb, (double*)dout);
+  } else {
+    PH_TRY(allow_lds(ph::k_sweep<float>, lds));
+    hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
+                       mode, chunks, kflags, tb, (double*)dout);
+  }
+  PH_TRY(launch_check("k_sweep"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- m_best
+int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, int min_length, int max_length,
+              int gamma, const int32_t* orth_off, const int32_t* orth_q, const int32_t* fac_off,
+              const int32_t* fac_q, int table_max_p, unsigned flags, uint32_t* periods, double* powers,
+              void* bases, int32_t* status) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!periods || !powers || !bases || !status) return fail(PH_E_ARG, "output pointer is NULL");
+  if (num < 1 || num > 4096) return fail(PH_E_ARG, "num=%d must be in [1, 4096]", num);
+  if (max_length < 0) max_length = N / 3;  // Periods.py:485-486
+  if (min_length < 1 || max_length < min_length)
+    return fail(PH_E_ARG, "need 1 <= min_length <= max_length (got %d, %d)", min_length, max_length);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  const int P = max_length - min_length + 1;
+  size_t lds1 = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+                carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) + carve_bytes(num, 8) +
+                carve_bytes(num, 4) + carve_bytes((P + 31) / 32, 4);
+  size_t lds2 = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(num, 8) + carve_bytes(num, 4);
+  PH_TRY(check_lds(c, std::max(lds1, lds2), N, "ph_m_best"));
+  ph::Tables tb{};
+  PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, max_length, &tb));
+  PH_TRY(prepare_fac(c, fac_off, fac_q, table_max_p, max_length, &tb));
+  Stage st(c, flags);
+  const void* dx;
+  void *dper, *dpow, *dbases, *dstat;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, periods, (size_t)W * num * sizeof(uint32_t), &dper));
+  PH_TRY(st.out(B_OUT1, powers, (size_t)W * num * sizeof(double), &dpow));
+  PH_TRY(st.out(B_OUT2, bases, (size_t)W * num * N * sz, &dbases));
+  PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
+  PH_TRY(ensure(c, c->buf[B_WS0], (size_t)W * sizeof(double)));
+  double* dnorm = static_cast<double*>(c->buf[B_WS0].p);
+  const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  const int max_iters = 12 * (P + num) + 64;
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_mbest_step1<double>, lds1));
+    PH_TRY(allow_lds(ph::k_mbest_step2<double>, lds2));
+    hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(kBlock), lds1, c->stream, (const double*)dx, N, num,
+                       min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
+                       (double*)dbases, dnorm, (int*)dstat);
+    PH_TRY(launch_check("k_mbest_step1"));
+    hipLaunchKernelGGL(ph::k_mbest_step2<double>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
+                       kflags, tb, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
+  } else {
+    PH_TRY(allow_lds(ph::k_mbest_step1<float>, lds1));
+    PH_TRY(allow_lds(ph::k_mbest_step2<float>, lds2));
+    hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(kBlock), lds1, c->stream, (const float*)dx, N, num,
+                       min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
+                       (float*)dbases, dnorm, (int*)dstat);
+    PH_TRY(launch_check("k_mbest_step1"));
+    hipLaunchKernelGGL(ph::k_mbest_step2<float>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
+                       kflags, tb, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
+  }
+  PH_TRY(launch_check("k_mbest_step2"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- small_to_large
+int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, double thresh, int n_periods,
+                      const int32_t* orth_off, const int32_t* orth_q, int table_max_p, unsigned flags, int cap,
+                      int32_t* counts, int32_t* periods, double* powers, void* bases, int32_t* status) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!counts || !periods || !powers || !status) return fail(PH_E_ARG, "output pointer is NULL");
+  if (cap < 1) return fail(PH_E_ARG, "cap=%d must be >= 1", cap);
+  if (n_periods < 0) n_periods = N / 2;  // Periods.py:271-272
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  size_t lds = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+               carve_bytes(kBlock, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_small_to_large"));
+  ph::Tables tb{};
+  PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, std::max(n_periods, 1), &tb));
+  Stage st(c, flags);
+  const void* dx;
+  void *dcnt, *dper, *dpow, *dbases, *dstat;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, counts, (size_t)W * sizeof(int32_t), &dcnt));
+  PH_TRY(st.out(B_OUT1, periods, (size_t)W * cap * sizeof(int32_t), &dper));
+  PH_TRY(st.out(B_OUT2, powers, (size_t)W * cap * sizeof(double), &dpow));
+  PH_TRY(st.out(B_OUT3, bases, (size_t)W * cap * N * sz, &dbases));
+  PH_TRY(st.out(B_OUT4, status, (size_t)W * sizeof(int32_t), &dstat));
+  PH_HIP(hipMemsetAsync(dper, 0, (size_t)W * cap * sizeof(int32_t), c->stream));
+  PH_HIP(hipMemsetAsync(dpow, 0, (size_t)W * cap * sizeof(double), c->stream));
+  const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_small_to_large<double>, lds));
+    hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
+                       thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow,
+                       (double*)dbases, (int*)dstat);
+  } else {
+    PH_TRY(allow_lds(ph::k_small_to_large<float>, lds));
+    hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
+                       thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
+                       (int*)dstat);
+  }
+  PH_TRY(launch_check("k_small_to_large"));
+  PH_TRY(st.finish());
+  if (!(flags & PH_FLAG_DEVICE)) {
+    int worst = 0;
+    for (int64_t w = 0; w < W; ++w) worst = std::max(worst, counts[w]);
+    if (worst > cap) return fail(PH_E_CAP, "a window accepted %d periods, cap is %d", worst, cap);
+  }
+  return PH_OK;
+}
+
+// ----------------------------------------------------------------------------- best_correlation
+int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, int max_length,
+                        double ratio, const int32_t* orth_off, const int32_t* orth_q, int table_max_p,
+                        unsigned flags, uint32_t* periods, double* norms, void* bases, int32_t* status) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!periods || !norms || !bases || !status) return fail(PH_E_ARG, "output pointer is NULL");
+  if (num < 1) return fail(PH_E_ARG, "num=%d must be >= 1", num);
+  if (max_length < 0) max_length = N / 3;  // Periods.py:311-312
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  size_t lds = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+               carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+  PH_TRY(check_lds(c, lds, N, "ph_best_correlation"));
+  ph::Tables tb{};
+  PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, std::max(max_length, 1), &tb));
+  Stage st(c, flags);
+  const void* dx;
+  void *dper, *dnrm, *dbases, *dstat;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, periods, (size_t)W * num * sizeof(uint32_t), &dper));
+  PH_TRY(st.out(B_OUT1, norms, (size_t)W * num * sizeof(double), &dnrm));
+  PH_TRY(st.out(B_OUT2, bases, (size_t)W * num * N * sz, &dbases));
+  PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
+  const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_best_correlation<double>, lds));
+    hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
+                       num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
+                       (int*)dstat);
+  } else {
+    PH_TRY(allow_lds(ph::k_best_correlation<float>, lds));
+    hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
+                       num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
+                       (int*)dstat);
+  }
+  PH_TRY(launch_check("k_best_correlation"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- Ramanujan
+int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int q_lo, int q_hi,
+                       unsigned flags, double* out) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!out) return fail(PH_E_ARG, "out is NULL");
+  if (q_lo < 1 || q_hi < 1) return fail(PH_E_ARG, "need q_lo, q_hi >= 1 (got %d, %d)", q_lo, q_hi);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const int nw = kBlock / 64;
+  size_t lds = carve_bytes(N, sz) + 3 * carve_bytes((size_t)nw * q_hi, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
+  // integer tables: Moebius mu, Euler phi, and for every q the divisors d with mu(q/d) != 0
+  std::vector<int32_t> mu(q_hi + 1, 1), phi(q_hi + 1), off(q_hi + 2, 0), dd, dm;
+  {
+    std::vector<char> comp(q_hi + 1, 0);
+    for (int i = 0; i <= q_hi; ++i) phi[i] = i;
+    for (int i = 2; i <= q_hi; ++i) {
+      if (comp[i]) continue;
+      for (int j = i; j <= q_hi; j += i) {
+        comp[j] = j > i;
+        mu[j] = -mu[j];
+        phi[j] -= phi[j] / i;
+      }
+      const int64_t sq = (int64_t)i * i;
+      for (int64_t j = sq; j <= q_hi; j += sq) mu[j] = 0;
+    }
+    for (int q = 1; q <= q_hi; ++q) {
+      off[q] = (int32_t)dd.size();
+      for (int d = 1; d <= q; ++d)
+        if (q % d == 0 && mu[q / d] != 0) {
+          dd.push_back(d);
+          dm.push_back(mu[q / d]);
+        }
+    }
+    off[0] = 0;
+    off[q_hi + 1] = (int32_t)dd.size();
+  }
+  const int *d_off, *d_d, *d_mu, *d_phi;
+  PH_TRY(upload_table(c, T_AUX0, off.data(), off.size(), &d_off));
+  PH_TRY(upload_table(c, T_AUX1, dd.data(), dd.size(), &d_d));
+  PH_TRY(upload_table(c, T_AUX2, dm.data(), dm.size(), &d_mu));
+  PH_TRY(upload_table(c, T_AUX3, phi.data(), phi.size(), &d_phi));
+  Stage st(c, flags);
+  const void* dx;
+  void* dout;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, out, (size_t)W * (q_hi + 1) * sizeof(double), &dout));
+  PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * (q_hi + 1) * sizeof(double), c->stream));
+  const dim3 grid((unsigned)W);
+  if (q_lo <= q_hi) {
+    if (dtype == PH_F64) {
+      PH_TRY(allow_lds(ph::k_ramanujan<double>, lds));
+      hipLaunchKernelGGL(ph::k_ramanujan<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, q_lo,
+                         q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+    } else {
+      PH_TRY(allow_lds(ph::k_ramanujan<float>, lds));
+      hipLaunchKernelGGL(ph::k_ramanujan<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, q_lo,
+                         q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+    }
+    PH_TRY(launch_check("k_ramanujan"));
+  }
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- QOPeriods blocks
+static int qo_tables(ph_ctx* c, const int32_t* p_list, const int32_t* keep, int n_p, const int** d_p,
+                     const int** d_keep, const int** d_off, int* stride) {
+  if (!p_list || !keep || n_p < 1) return fail(PH_E_ARG, "p_list/keep NULL or n_p < 1");
+  std::vector<int32_t> off(n_p + 1, 0);
+  for (int k = 0; k < n_p; ++k) {
+    if (p_list[k] < 1 || keep[k] < 0 || keep[k] > p_list[k])
+      return fail(PH_E_ARG, "need p >= 1 and 0 <= keep <= p at entry %d", k);
+    off[k + 1] = off[k] + keep[k];
+  }
+  *stride = off[n_p];
+  if (*stride < 1) return fail(PH_E_ARG, "sum(keep) must be >= 1");
+  PH_TRY(upload_table(c, T_PLIST, p_list, n_p, d_p));
+  PH_TRY(upload_table(c, T_AUX0, keep, n_p, d_keep));
+  PH_TRY(upload_table(c, T_AUX1, off.data(), off.size(), d_off));
+  return PH_OK;
+}
+
+int ph_fold_sums(ph_ctx* c, const void* x, int dtype, int64_t W, int N, const int32_t* p_list,
+                 const int32_t* keep, int n_p, unsigned flags, double* out) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!out) return fail(PH_E_ARG, "out is NULL");
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const size_t lds = carve_bytes(N, sz);
+  PH_TRY(check_lds(c, lds, N, "ph_fold_sums"));
+  const int *d_p, *d_keep, *d_off;
+  int stride;
+  PH_TRY(qo_tables(c, p_list, keep, n_p, &d_p, &d_keep, &d_off, &stride));
+  Stage st(c, flags);
+  const void* dx;
+  void* dout;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, out, (size_t)W * stride * sizeof(double), &dout));
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_fold_sums<double>, lds));
+    hipLaunchKernelGGL(ph::k_fold_sums<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, d_p,
+                       d_keep, d_off, n_p, stride, (double*)dout);
+  } else {
+    PH_TRY(allow_lds(ph::k_fold_sums<float>, lds));
+    hipLaunchKernelGGL(ph::k_fold_sums<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, d_p,
+                       d_keep, d_off, n_p, stride, (double*)dout);
+  }
+  PH_TRY(launch_check("k_fold_sums"));
+  return st.finish();
+}
+
+int ph_tile_sum(ph_ctx* c, const double* wts, int64_t W, int N, const int32_t* p_list, const int32_t* keep,
+                int n_p, int dtype, unsigned flags, void* out) {
+  PH_TRY(check_common(c, wts, dtype, W, N));
+  if (!out) return fail(PH_E_ARG, "out is NULL");
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const int *d_p, *d_keep, *d_off;
+  int stride;
+  PH_TRY(qo_tables(c, p_list, keep, n_p, &d_p, &d_keep, &d_off, &stride));
+  const size_t lds = carve_bytes(stride, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_tile_sum"));
+  Stage st(c, flags);
+  const void* dw;
+  void* dout;
+  PH_TRY(st.in(wts, (size_t)W * stride * sizeof(double), &dw));
+  PH_TRY(st.out(B_OUT0, out, (size_t)W * N * sz, &dout));
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_tile_sum<double>, lds));
+    hipLaunchKernelGGL(ph::k_tile_sum<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dw, N, d_p,
+                       d_keep, d_off, n_p, stride, (double*)dout);
+  } else {
+    PH_TRY(allow_lds(ph::k_tile_sum<float>, lds));
+    hipLaunchKernelGGL(ph::k_tile_sum<float>, grid, dim3(kBlock), lds, c->stream, (const double*)dw, N, d_p,
+                       d_keep, d_off, n_p, stride, (float*)dout);
+  }
+  PH_TRY(launch_check("k_tile_sum"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- periodic_norm
+int ph_periodic_norm(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p, unsigned flags,
+                     double* out) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!out) return fail(PH_E_ARG, "out is NULL");
+  if (p < 0) return fail(PH_E_ARG, "p=%d must be >= 0 (0 = no period normalisation)", p);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  Stage st(c, flags);
+  const void* dx;
+  void* dout;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, out, (size_t)W * sizeof(double), &dout));
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64)
+    hipLaunchKernelGGL(ph::k_periodic_norm<double>, grid, dim3(kBlock), 0, c->stream, (const double*)dx, N, p,
+                       (double*)dout);
+  else
+    hipLaunchKernelGGL(ph::k_periodic_norm<float>, grid, dim3(kBlock), 0, c->stream, (const float*)dx, N, p,
+                       (double*)dout);
+  PH_TRY(launch_check("k_periodic_norm"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- dictionary project
+int ph_dict_project(ph_ctx* c, const double* x, const double* basis, int rows, int N, unsigned flags,
+                    float* out) {
+  if (!c || !x || !basis || !out) return fail(PH_E_ARG, "NULL argument");
+  if (rows < 1 || N < 1) return fail(PH_E_ARG, "rows=%d, N=%d must be >= 1", rows, N);
+  PH_HIP(hipSetDevice(c->device));
+  const bool device = flags & PH_FLAG_DEVICE;
+  const double *dx = x, *db = basis;
+  float* dout = out;
+  if (!device) {
+    PH_TRY(ensure(c, c->buf[B_IN], (size_t)N * 8));
+    PH_TRY(ensure(c, c->buf[B_WS1], (size_t)rows * N * 8));
+    PH_TRY(ensure(c, c->buf[B_OUT0], (size_t)rows * N * 4));
+    PH_HIP(hipMemcpyAsync(c->buf[B_IN].p, x, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+    PH_HIP(hipMemcpyAsync(c->buf[B_WS1].p, basis, (size_t)rows * N * 8, hipMemcpyHostToDevice, c->stream));
+    dx = (const double*)c->buf[B_IN].p;
+    db = (const double*)c->buf[B_WS1].p;
+    dout = (float*)c->buf[B_OUT0].p;
+  }
+  hipLaunchKernelGGL(ph::k_dict_project, dim3((unsigned)rows), dim3(kBlock), 0, c->stream, dx, db, N, dout);
+  PH_TRY(launch_check("k_dict_project"));
+  if (!device) {
+    PH_HIP(hipMemcpyAsync(out, dout, (size_t)rows * N * 4, hipMemcpyDeviceToHost, c->stream));
+    PH_HIP(hipStreamSynchronize(c->stream));
+  }
+  return PH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,783 @@
+// Kernels of libperiod_hip.so.  One workgroup owns one signal window (or one window and a
+// slice of the candidate periods); the window is read from HBM once and lives in LDS for the
+// whole algorithm.  Reference citations are file:line into /root/reference/pyPeriod/.
+#pragma once
+
+#include <type_traits>
+
+#include "ph_device.h"
+
+namespace ph {
+
+// Dynamic LDS carve-up; every piece starts 16-byte aligned (guide: Guideline 17).
+struct Carve {
+  unsigned char* base;
+  size_t off;
+  __device__ explicit Carve(unsigned char* b) : base(b), off(0) {}
+  template <typename U>
+  __device__ U* take(size_t n) {
+    U* p = reinterpret_cast<U*>(base + off);
+    off += (n * sizeof(U) + 15) & ~size_t(15);
+    return p;
+  }
+};
+
+__host__ __device__ inline size_t carve_bytes(size_t n, size_t elem) { return (n * elem + 15) & ~size_t(15); }
+
+constexpr int kRedDoubles = 2 * kMaxWaves;
+
+// ======================================================================================
+// K1  Periods.project over a batch  (Periods.py:142-219)
+//   grid.x = W * chunks; each workgroup projects its window onto p_list[k0 .. k1).
+//   Non-orth: means stay in registers and rows stream straight to HBM (write-bound).
+//   Orth: projection is materialised in a second LDS buffer, sub-projections removed there.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ x, int N,
+                                                          const int* __restrict__ p_list, int n_p, int chunks,
+                                                          unsigned flags, Tables tb, T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* xs = cv.take<T>(N);
+  T* buf = (flags & kOrth) ? cv.take<T>(N) : nullptr;
+
+  const int64_t w = blockIdx.x / chunks;
+  const int c = blockIdx.x % chunks;
+  const int per = (n_p + chunks - 1) / chunks;
+  const int k0 = c * per;
+  const int k1 = min(n_p, k0 + per);
+  load_window(x + w * (int64_t)N, xs, N);
+  __syncthreads();
+
+  const bool trunc = flags & kTrunc;
+  const bool single = flags & kSingle;
+  for (int k = k0; k < k1; ++k) {
+    const int p = p_list[k];
+    T* orow = out + (w * n_p + k) * (int64_t)N;
+    if (!(flags & kOrth)) {
+      const Fold f(N, p);
+      for (int j = threadIdx.x; j < p; j += blockDim.x) {
+        const T m = residue_mean(xs, f, j, trunc);
+        const int cnt = single ? (j < N ? 1 : 0) : f.count(j);
+        for (int r = 0; r < cnt; ++r) orow[r * p + j] = m;
+      }
+    } else {
+      project_lds(xs, buf, N, p, flags, tb);
+      const int lim = single ? min(p, N) : N;
+      for (int n = threadIdx.x; n < lim; n += blockDim.x) orow[n] = buf[n];
+      __syncthreads();  // buf is rewritten by the next period
+    }
+  }
+}
+
+// ======================================================================================
+// K2  fused all-p sweep  (inner loops Periods.py:501-510, :324-331)
+//   grid.x = W * chunks.  Fast path (no flags): wave-per-period, no workgroup barrier after
+//   the window load.  Flagged path: workgroup-cooperative full projection per period.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
+                                                  int chunks, unsigned flags, Tables tb,
+                                                  double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* xs = cv.take<T>(N);
+  const bool general = (flags & (kTrunc | kOrth)) && mode != 2;
+  T* buf = general ? cv.take<T>(N) : nullptr;
+  double* red = cv.take<double>(kRedDoubles);
+
+  const int64_t w = blockIdx.x / chunks;
+  const int c = blockIdx.x % chunks;
+  const int P = p_hi - p_lo + 1;
+  const int per = (P + chunks - 1) / chunks;
+  const int pa = p_lo + c * per;
+  const int pb = min(p_hi, pa + per - 1);
+  load_window(x + w * (int64_t)N, xs, N);
+  __syncthreads();
+  double* orow = out + w * (int64_t)P;
+
+  if (!general) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    for (int p = pa + wv; p <= pb; p += nw) {
+      double v;
+      if (mode == 2) {
+        v = wave_fold_maxabs(xs, N, p, lane);
+      } else {
+        v = periodic_norm_from_sq(wave_proj_sq(xs, N, p, lane), N, mode == 1 ? p : 0);
+      }
+      if (lane == 0) orow[p - p_lo] = v;
+    }
+  } else {
+    for (int p = pa; p <= pb; ++p) {
+      const double v = block_sweep_value(xs, buf, N, p, mode == 1 ? p : 0, flags, tb, red);
+      if (threadIdx.x == 0) orow[p - p_lo] = v;
+    }
+  }
+}
+
+// ======================================================================================
+// m_best step 1  (Periods.py:494-537): repeat { all-p sweep, argmax, subtract } until `num`
+// distinct periods are found.  One workgroup per window, one launch per window batch.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
+                                                        int p_hi, int gamma, unsigned flags, Tables tb,
+                                                        int max_iters, uint32_t* __restrict__ periods_out,
+                                                        double* __restrict__ norms_out, T* __restrict__ bases_out,
+                                                        double* __restrict__ dnorm_out,
+                                                        int* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* work = cv.take<T>(N);
+  const bool general = flags & (kTrunc | kOrth);
+  T* buf = general ? cv.take<T>(N) : nullptr;
+  double* red = cv.take<double>(kRedDoubles);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  double* norms = cv.take<double>(num);
+  uint32_t* periods = cv.take<uint32_t>(num);
+  const int P = p_hi - p_lo + 1;
+  uint32_t* skip = cv.take<uint32_t>((P + 31) / 32);
+
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = tid >> 6;
+  const int nw = blockDim.x >> 6;
+  T* bases = bases_out + w * (int64_t)num * N;
+
+  load_window(x + w * (int64_t)N, work, N);
+  for (int k = tid; k < num; k += blockDim.x) {
+    norms[k] = 0.0;
+    periods[k] = 0u;
+  }
+  for (int k = tid; k < (P + 31) / 32; k += blockDim.x) skip[k] = 0u;
+  __syncthreads();
+  // rows the algorithm never fills stay zero, like np.zeros((num, N)) at Periods.py:490
+  for (int64_t n = tid; n < (int64_t)num * N; n += blockDim.x) bases[n] = T(0);
+  const double data_norm = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
+
+  int filled = 0;   // `i` of Periods.py:494
+  int repeats = 0;  // `iters`
+  int status = 0;
+  int iters = 0;
+  while (filled < num) {
+    if (++iters > max_iters) {
+      status = 2;
+      break;
+    }
+    // ---- sweep (Periods.py:501-515): strict '>' keeps the lowest p among equal norms
+    double best = 0.0;
+    int bestp = 0;
+    if (!general) {
+      for (int p = p_lo + wv; p <= p_hi; p += nw) {
+        const double v = periodic_norm_from_sq(wave_proj_sq(work, N, p, lane), N, gamma ? p : 0);
+        const bool skipped = (skip[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u;
+        if (v > best && !skipped) {
+          best = v;
+          bestp = p;
+        }
+      }
+      if (lane == 0) {
+        wbest[wv] = best;
+        wbestp[wv] = bestp;
+      }
+      __syncthreads();
+      best = 0.0;
+      bestp = 0;
+      for (int i = 0; i < nw; ++i) {
+        const double v = wbest[i];
+        const int pp = wbestp[i];
+        if (pp != 0 && (v > best || (v == best && pp < bestp))) {
+          best = v;
+          bestp = pp;
+        }
+      }
+      __syncthreads();
+    } else {
+      for (int p = p_lo; p <= p_hi; ++p) {
+        const double v = block_sweep_value(work, buf, N, p, gamma ? p : 0, flags, tb, red);
+        const bool skipped = (skip[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u;
+        if (v > best && !skipped) {
+          best = v;
+          bestp = p;
+        }
+      }
+    }
+    if (bestp == 0) {  // reference: max_base is None -> TypeError at Periods.py:520/537
+      status = 1;
+      break;
+    }
+    // ---- bookkeeping (Periods.py:518-535); identical in every thread
+    int row = -1;
+    for (int k = 0; k < num; ++k)
+      if (periods[k] == (uint32_t)bestp) row = k;
+    int action;  // 0 = subtract only, 1 = store new row, 2 = accumulate into existing row
+    __syncthreads();
+    if (row >= 0 && repeats < 10) {
+      action = 2;
+      if (tid == 0) norms[row] += best;
+      repeats += 1;
+    } else if (row >= 0) {
+      action = 0;
+      if (tid == 0) skip[(bestp - p_lo) >> 5] |= 1u << ((bestp - p_lo) & 31);
+      repeats = 0;
+    } else {
+      action = 1;
+      row = filled;
+      if (tid == 0) {
+        periods[row] = (uint32_t)bestp;
+        norms[row] = best;
+      }
+      filled += 1;
+      repeats = 0;
+    }
+    // ---- project the winner, update bases row, subtract from the residual (:531-537)
+    T* brow = bases + (int64_t)(row < 0 ? 0 : row) * N;
+    if (!general) {
+      const Fold f(N, bestp);
+      for (int j = tid; j < bestp; j += blockDim.x) {
+        const T m = residue_mean(work, f, j, false);
+        const int cnt = f.count(j);
+        for (int r = 0; r < cnt; ++r) {
+          const int n = r * bestp + j;
+          if (action == 1)
+            brow[n] = m;
+          else if (action == 2)
+            brow[n] += m;
+          work[n] -= m;
+        }
+      }
+    } else {
+      project_lds(work, buf, N, bestp, flags, tb);
+      for (int n = tid; n < N; n += blockDim.x) {
+        const T m = buf[n];
+        if (action == 1)
+          brow[n] = m;
+        else if (action == 2)
+          brow[n] += m;
+        work[n] -= m;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int k = tid; k < num; k += blockDim.x) {
+    periods_out[w * num + k] = periods[k];
+    norms_out[w * num + k] = norms[k];
+  }
+  if (tid == 0) {
+    dnorm_out[w] = data_norm;
+    status_out[w] = status;
+  }
+}
+
+// ======================================================================================
+// m_best step 2  (Periods.py:540-598): factor refinement, including the reference's
+// quirks: stale `p` in gamma mode (:559,572), `nq` = norm of the LAST factor's projection
+// (:569-572), no advance of i after a split (:581-594).  One workgroup per window.
+// norms_io holds raw norms on entry and powers (norms / ||data||, :600) on exit.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
+                                                        Tables tb, uint32_t* __restrict__ periods_io,
+                                                        double* __restrict__ norms_io, T* __restrict__ bases_io,
+                                                        const double* __restrict__ dnorm,
+                                                        const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* rowbuf = cv.take<T>(N);
+  T* buf = cv.take<T>(N);
+  double* red = cv.take<double>(kRedDoubles);
+  double* norms = cv.take<double>(num);
+  uint32_t* periods = cv.take<uint32_t>(num);
+
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  T* bases = bases_io + w * (int64_t)num * N;
+  for (int k = tid; k < num; k += blockDim.x) {
+    norms[k] = norms_io[w * num + k];
+    periods[k] = periods_io[w * num + k];
+  }
+  __syncthreads();
+
+  const int gdiv = gamma ? stale_p : 0;
+  int i = (status[w] == 0) ? 0 : num;  // a window whose step 1 failed is passed through
+  while (i < num) {
+    const int per = (int)periods[i];
+    load_window(bases + (int64_t)i * N, rowbuf, N);
+    __syncthreads();
+    double top = 0.0, last = 0.0;
+    int topf = -1;
+    const int a = tb.fac_off[per], b = tb.fac_off[per + 1];
+    for (int k = a; k < b; ++k) {
+      const int f = tb.fac_q[k];
+      const double v = block_sweep_value(rowbuf, buf, N, f, gdiv, flags, tb, red);
+      if (v > top) {
+        top = v;
+        topf = f;
+      }
+      last = v;
+    }
+    bool split = false;
+    if (topf >= 0) {
+      bool present = false;
+      for (int k = 0; k < num; ++k) present |= (periods[k] == (uint32_t)topf);
+      if (!present) {
+        double floor_q = norms[0];
+        for (int k = 1; k < num; ++k) floor_q = fmin(floor_q, norms[k]);
+        split = (last + top) > (norms[num - 1] + norms[i]) && last > floor_q && top > floor_q;
+      }
+    }
+    __syncthreads();
+    if (!split) {
+      i += 1;
+      continue;
+    }
+    // recompute the winning factor's projection (bit-identical), then
+    //   rows i+2.. <- rows i+1.. ; row i+1 <- row i - proj ; row i <- proj   (:581-594)
+    project_lds(rowbuf, buf, N, topf, flags, tb);
+    for (int r = num - 1; r >= i + 2; --r) {
+      T* dst = bases + (int64_t)r * N;
+      const T* src = bases + (int64_t)(r - 1) * N;
+      for (int n = tid; n < N; n += blockDim.x) dst[n] = src[n];
+    }
+    if (i + 1 < num) {
+      T* dst = bases + (int64_t)(i + 1) * N;
+      for (int n = tid; n < N; n += blockDim.x) dst[n] = rowbuf[n] - buf[n];
+    }
+    {
+      T* dst = bases + (int64_t)i * N;
+      for (int n = tid; n < N; n += blockDim.x) dst[n] = buf[n];
+    }
+    if (tid == 0) {
+      for (int r = num - 1; r >= i + 2; --r) {
+        norms[r] = norms[r - 1];
+        periods[r] = periods[r - 1];
+      }
+      if (i + 1 < num) {
+        norms[i + 1] = last;  // the old row keeps its period, weakened (:582-584)
+        periods[i + 1] = (uint32_t)per;
+      }
+      norms[i] = top;
+      periods[i] = (uint32_t)topf;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  __syncthreads();
+  const double dn = dnorm[w];
+  for (int k = tid; k < num; k += blockDim.x) {
+    periods_io[w * num + k] = periods[k];
+    norms_io[w * num + k] = norms[k] / dn;
+  }
+}
+
+// ======================================================================================
+// Periods.small_to_large  (Periods.py:246-287).  Sequential in p; one workgroup per window.
+//   Plain projection: screen every p with ||r - P r||^2 = ||r||^2 - ||P r||^2 (one LDS pass),
+//   and evaluate the reference's expression exactly (second pass) whenever the screen is
+//   within its own error bound of the threshold, so the accept decision is the exact one.
+// ======================================================================================
+template <typename T>
+__device__ __forceinline__ double block_proj_sq(const T* __restrict__ xs, int N, int p, double* scratch,
+                                                double* red) {
+  const Fold f(N, p);
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  double a = 0.0, b = 0.0;
+  if (p >= nthr) {
+    for (int j = tid; j < p; j += nthr) {
+      const bool full = j < f.nfull;
+      const double s = (double)column_sum(xs, j, p, full ? f.rows : f.rows - 1);
+      if (full)
+        a += s * s;
+      else
+        b += s * s;
+    }
+  } else {
+    // G row groups of p lanes: thread t sums x[t], x[t+L], ... with L = G*p (contiguous reads)
+    const int G = nthr / p;
+    const int L = G * p;
+    double part = 0.0;
+    if (tid < L)
+      for (int n = tid; n < N; n += L) part += (double)xs[n];
+    scratch[tid] = part;
+    __syncthreads();
+    if (tid < p) {
+      double s = 0.0;
+      for (int g = 0; g < G; ++g) s += scratch[tid + g * p];
+      if (tid < f.nfull)
+        a = s * s;
+      else
+        b = s * s;
+    }
+  }
+  block_sum2(a, b, red);
+  double v = a / (double)f.rows;
+  if (f.rows > 1) v += b / (double)(f.rows - 1);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
+                                                           int n_periods, unsigned flags, Tables tb, int cap,
+                                                           int* __restrict__ counts, int* __restrict__ periods_out,
+                                                           double* __restrict__ powers_out,
+                                                           T* __restrict__ bases_out, int* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* work = cv.take<T>(N);
+  const bool general = flags & (kTrunc | kOrth);
+  T* buf = general ? cv.take<T>(N) : nullptr;
+  double* red = cv.take<double>(kRedDoubles);
+  double* scratch = cv.take<double>(kBlock);
+
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  load_window(x + w * (int64_t)N, work, N);
+  __syncthreads();
+  double rsq = block_sumsq(work, N, red);
+  const double sqrtN = sqrt((double)N);
+  const double dn = sqrt(rsq) / sqrtN;  // data_norm, Periods.py:269
+  double rn = dn;                       // periodic_norm(residual)
+  int count = 0;
+
+  for (int p = 2; p <= n_periods; ++p) {
+    bool evaluate = true;
+    if (!general) {
+      const double psq = block_proj_sq(work, N, p, scratch, red);
+      const double tsq = fmax(rsq - psq, 0.0);
+      const double tn_est = sqrt(tsq) / sqrtN;
+      const double est = (rn - tn_est) / dn;
+      // error of tn_est from the cancellation in rsq - psq, relative to data_norm
+      const double err = (16.0 * 2.220446049250313e-16 * rsq / fmax(sqrt(tsq), 1e-300)) / sqrtN / dn + 1e-13;
+      evaluate = !(est + err <= thresh);  // NaN -> evaluate
+    }
+    if (!evaluate) continue;
+    // exact evaluation of Periods.py:274-281
+    double tsq = 0.0;
+    if (!general) {
+      const Fold f(N, p);
+      for (int j = tid; j < p; j += blockDim.x) {
+        const T m = residue_mean(work, f, j, false);
+        const int cnt = f.count(j);
+        for (int r = 0; r < cnt; ++r) {
+          const double t = (double)(work[r * p + j] - m);
+          tsq += t * t;
+        }
+      }
+    } else {
+      project_lds(work, buf, N, p, flags, tb);
+      for (int n = tid; n < N; n += blockDim.x) {
+        const double t = (double)(work[n] - buf[n]);
+        tsq += t * t;
+      }
+    }
+    tsq = block_sum(tsq, red);
+    const double tn = sqrt(tsq) / sqrtN;
+    const double imposed = (rn - tn) / dn;
+    if (imposed > thresh) {  // strict, Periods.py:281
+      T* brow = (bases_out && count < cap) ? bases_out + (w * cap + count) * (int64_t)N : nullptr;
+      if (!general) {
+        const Fold f(N, p);
+        for (int j = tid; j < p; j += blockDim.x) {
+          const T m = residue_mean(work, f, j, false);
+          const int cnt = f.count(j);
+          for (int r = 0; r < cnt; ++r) {
+            const int n = r * p + j;
+            if (brow) brow[n] = m;
+            work[n] -= m;
+          }
+        }
+      } else {
+        for (int n = tid; n < N; n += blockDim.x) {
+          const T m = buf[n];
+          if (brow) brow[n] = m;
+          work[n] -= m;
+        }
+      }
+      if (tid == 0 && count < cap) {
+        periods_out[w * cap + count] = p;
+        powers_out[w * cap + count] = imposed;
+      }
+      count += 1;
+      rsq = tsq;
+      rn = tn;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    counts[w] = count;
+    status_out[w] = count > cap ? 3 : 0;
+  }
+}
+
+// ======================================================================================
+// Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_best_correlation(const T* __restrict__ x, int N, int num,
+                                                             int max_length, double ratio, unsigned flags,
+                                                             Tables tb, uint32_t* __restrict__ periods_out,
+                                                             double* __restrict__ norms_out,
+                                                             T* __restrict__ bases_out,
+                                                             int* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* work = cv.take<T>(N);
+  const bool general = flags & (kTrunc | kOrth);
+  T* buf = general ? cv.take<T>(N) : nullptr;
+  double* red = cv.take<double>(kRedDoubles);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = tid >> 6;
+  const int nw = blockDim.x >> 6;
+  T* bases = bases_out + w * (int64_t)num * N;
+  load_window(x + w * (int64_t)N, work, N);
+  __syncthreads();
+  const double sqrtN = sqrt((double)N);
+  const double og = sqrt(block_sumsq(work, N, red)) / sqrtN;  // :316
+  double old_norm = og;
+  int status = 0;
+
+  for (int i = 0; i < num; ++i) {
+    T* brow = bases + (int64_t)i * N;
+    uint32_t keep_p = 0u;
+    double keep_n = 0.0;
+    bool zero_row = true;
+    if (status == 0) {
+      // argmax over (p, s) of |sum(x[s::p])|, strict '>' in p-major order (:324-331)
+      double best = 0.0;
+      int bestp = 0;
+      for (int p = 2 + wv; p < max_length; p += nw) {
+        const double v = wave_fold_maxabs(work, N, p, lane);
+        if (v > best) {
+          best = v;
+          bestp = p;
+        }
+      }
+      if (lane == 0) {
+        wbest[wv] = best;
+        wbestp[wv] = bestp;
+      }
+      __syncthreads();
+      best = 0.0;
+      bestp = 0;
+      for (int k = 0; k < nw; ++k) {
+        const double v = wbest[k];
+        const int pp = wbestp[k];
+        if (pp != 0 && (v > best || (v == best && pp < bestp))) {
+          best = v;
+          bestp = pp;
+        }
+      }
+      __syncthreads();
+      if (bestp == 0) {
+        status = 1;  // reference: project(data, None) raises
+      } else {
+        // project, subtract unconditionally (:334-340)
+        if (!general) {
+          const Fold f(N, bestp);
+          for (int j = tid; j < bestp; j += blockDim.x) {
+            const T m = residue_mean(work, f, j, false);
+            const int cnt = f.count(j);
+            for (int r = 0; r < cnt; ++r) {
+              const int n = r * bestp + j;
+              brow[n] = m;
+              work[n] -= m;
+            }
+          }
+        } else {
+          project_lds(work, buf, N, bestp, flags, tb);
+          for (int n = tid; n < N; n += blockDim.x) {
+            const T m = buf[n];
+            brow[n] = m;
+            work[n] -= m;
+          }
+        }
+        __syncthreads();
+        const double this_norm = sqrt(block_sumsq(work, N, red)) / sqrtN;
+        const double gain = (old_norm - this_norm) / og;
+        if (gain > ratio) {  // :343
+          keep_p = (uint32_t)bestp;
+          keep_n = gain;
+          old_norm = this_norm;
+          zero_row = false;
+        }
+      }
+    }
+    if (zero_row)
+      for (int n = tid; n < N; n += blockDim.x) brow[n] = T(0);
+    if (tid == 0) {
+      periods_out[w * num + i] = keep_p;
+      norms_out[w * num + i] = keep_n;
+    }
+  }
+  if (tid == 0) status_out[w] = status;
+}
+
+// ======================================================================================
+// RamanujanPeriods.find_periods  (RamanujanPeriods.py:67-86, :124-169), folded form.
+//   Rows of the reference dictionary are shifts of c_q / phi(q) (the row / max(row) at :129
+//   cancels the L2 normalisation of :168).  With S = fold of x to period q:
+//     a = S (star) c_q / phi,  out = a (*) c_q / phi  ==  (q/phi)^2 * E_q S,
+//   where E_q = sum_{d | q} mu(q/d) * (mean over the q/d cosets mod d) is the projector onto
+//   the Ramanujan subspace; norms[q] = sum_j cnt_q[j] * out_j^2.  wave-per-q; div tables
+//   (d, mu(q/d)) per q come from the host side of the library.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ramanujan(const T* __restrict__ x, int N, int q_lo, int q_hi,
+                                                      const int* __restrict__ div_off,
+                                                      const int* __restrict__ div_d,
+                                                      const int* __restrict__ div_mu,
+                                                      const int* __restrict__ totient,
+                                                      double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* xs = cv.take<T>(N);
+  const int nw = blockDim.x >> 6;
+  const int wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1);
+  double* sbuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // S_q
+  double* obuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // filtered
+  double* fbuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // fold of S to d
+
+  const int64_t w = blockIdx.x;
+  load_window(x + w * (int64_t)N, xs, N);
+  double* orow = out + w * (int64_t)(q_hi + 1);
+  for (int q = threadIdx.x; q < q_lo && q <= q_hi; q += blockDim.x) orow[q] = 0.0;
+  __syncthreads();
+
+  for (int q = q_lo + wv; q <= q_hi; q += nw) {
+    const Fold f(N, q);
+    for (int j = lane; j < q; j += kWave) {
+      sbuf[j] = (double)column_sum(xs, j, q, f.count(j));
+      obuf[j] = 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int k = div_off[q]; k < div_off[q + 1]; ++k) {
+      const int d = div_d[k];
+      const double coef = (double)div_mu[k] * (double)d / (double)q;
+      const int reps = q / d;
+      for (int i = lane; i < d; i += kWave) {
+        double s = 0.0;
+        for (int r = 0; r < reps; ++r) s += sbuf[i + r * d];
+        fbuf[i] = s * coef;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (int j = lane; j < q; j += kWave) obuf[j] += fbuf[j % d];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const double scale = (double)q / (double)totient[q];
+    const double s2 = scale * scale;
+    double acc = 0.0;
+    for (int j = lane; j < q; j += kWave) {
+      const double o = obuf[j] * s2;
+      acc += (double)f.count(j) * o * o;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) orow[q] = acc;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// ======================================================================================
+// QOPeriods building blocks (QOPeriods.py:779-795): W = A x and A^T w for natural-basis A.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fold_sums(const T* __restrict__ x, int N,
+                                                      const int* __restrict__ p_list,
+                                                      const int* __restrict__ keep,
+                                                      const int* __restrict__ row_off, int n_p, int stride,
+                                                      double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* xs = cv.take<T>(N);
+  const int64_t w = blockIdx.x;
+  load_window(x + w * (int64_t)N, xs, N);
+  __syncthreads();
+  double* orow = out + w * (int64_t)stride;
+  for (int k = 0; k < n_p; ++k) {
+    const int p = p_list[k];
+    const Fold f(N, p);
+    for (int j = threadIdx.x; j < keep[k]; j += blockDim.x)
+      orow[row_off[k] + j] = (double)column_sum(xs, j, p, f.count(j));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ wts, int N,
+                                                     const int* __restrict__ p_list,
+                                                     const int* __restrict__ keep,
+                                                     const int* __restrict__ row_off, int n_p, int stride,
+                                                     T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* ws = reinterpret_cast<double*>(smem);
+  const int64_t w = blockIdx.x;
+  for (int i = threadIdx.x; i < stride; i += blockDim.x) ws[i] = wts[w * (int64_t)stride + i];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < n_p; ++k) {  // row order of A, like np.matmul(A.T, w) sums over rows
+      const int j = n % p_list[k];
+      if (j < keep[k]) acc += ws[row_off[k] + j];
+    }
+    out[w * (int64_t)N + n] = (T)acc;
+  }
+}
+
+// ======================================================================================
+// Periods.periodic_norm over a batch (Periods.py:221-241); streams from HBM, any N.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_periodic_norm(const T* __restrict__ x, int N, int p_div,
+                                                          double* __restrict__ out) {
+  __shared__ double red[kRedDoubles];
+  const int64_t w = blockIdx.x;
+  const T* row = x + w * (int64_t)N;
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const double t = (double)row[n];
+    acc += t * t;
+  }
+  const double ss = block_sum(acc, red);
+  if (threadIdx.x == 0) out[w] = periodic_norm_from_sq(ss, N, p_div);
+}
+
+// ======================================================================================
+// RamanujanPeriods.project(x, basis) (RamanujanPeriods.py:124-131) for an arbitrary
+// dictionary: row <- row / max(row); out[i] = float32(dot(x, row) * row).  One workgroup
+// per dictionary row, rows streamed from HBM twice (max, then dot+scale from L2).
+// ======================================================================================
+__global__ __launch_bounds__(kBlock) void k_dict_project(const double* __restrict__ x,
+                                                         const double* __restrict__ basis, int N,
+                                                         float* __restrict__ out) {
+  __shared__ double red[kRedDoubles];
+  const int64_t i = blockIdx.x;
+  const double* row = basis + i * (int64_t)N;
+  double m = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) m = fmax(m, row[n]);
+  m = wave_max(m);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = red[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, red[k]);
+  __syncthreads();
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) acc += x[n] * (row[n] / m);
+  const double dot = block_sum(acc, red);
+  for (int n = threadIdx.x; n < N; n += blockDim.x) out[i * (int64_t)N + n] = (float)(dot * (row[n] / m));
+}
+
+}  // namespace ph

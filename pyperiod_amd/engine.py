@@ -1,0 +1,324 @@
+"""Batched host planner over the C ABI: one `PeriodEngine` per GPU.
+
+Every method takes a batch of independent signal windows, row-major ``(W, N)``:
+  * a numpy array  -> host-pointer call; the library stages data through its own device
+    buffers and returns numpy arrays (this is what the drop-in classes use);
+  * a torch CUDA tensor -> device-pointer call on torch's current stream; outputs are torch
+    tensors on the same device and nothing crosses PCIe (what bench.py and the sharded
+    multi-GPU path use).
+
+No arithmetic of the path happens here; this file only shapes arguments for
+``libperiod_hip.so`` and raises if the library or the GPU is missing.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _factors, _ffi
+
+_NP_DTYPES = {np.dtype(np.float64): _ffi.PH_F64, np.dtype(np.float32): _ffi.PH_F32}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class _Out:
+    """Allocates outputs next to the input (numpy or torch) and hands out raw addresses."""
+
+    def __init__(self, like):
+        self.torch = _is_torch(like)
+        if self.torch:
+            import torch
+
+            self._t = torch
+            self.device = like.device
+
+    def empty(self, shape, dtype):
+        if self.torch:
+            tdt = {
+                np.float64: self._t.float64,
+                np.float32: self._t.float32,
+                np.int32: self._t.int32,
+                np.uint32: self._t.int32,  # same bits; viewed back by the caller if needed
+            }[dtype]
+            return self._t.empty(shape, dtype=tdt, device=self.device)
+        return np.empty(shape, dtype=dtype)
+
+    @staticmethod
+    def addr(a):
+        if a is None:
+            return None
+        if _is_torch(a):
+            return a.data_ptr()
+        return a.ctypes.data
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data
+
+
+class PeriodEngine:
+    """Owns one ``ph_ctx`` (one GPU, one stream)."""
+
+    def __init__(self, device: int | None = None):
+        self._lib = _ffi.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        n = C.c_int(0)
+        _ffi.check(self._lib.ph_device_count(C.byref(n)))
+        if n.value < 1:
+            raise _ffi.PeriodHipError("no HIP device visible; pyperiod_amd has no CPU fallback")
+        self.device = device % n.value
+        ctx = C.c_void_p()
+        _ffi.check(self._lib.ph_create(self.device, C.byref(ctx)))
+        self._ctx = ctx
+        self._bound_stream = None
+        self._lock = threading.Lock()
+        cu, lds = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.ph_device_info(self._ctx, C.byref(cu), C.byref(lds)))
+        self.num_cu, self.lds_bytes = cu.value, lds.value
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.ph_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _prep(self, x):
+        """-> (array, dtype code, W, N, flags, out-factory); binds torch's stream if needed."""
+        if _is_torch(x):
+            import torch
+
+            if not x.is_cuda:
+                raise ValueError("torch input must live on the GPU (or pass a numpy array)")
+            if x.device.index != self.device:
+                raise ValueError(f"tensor on cuda:{x.device.index}, engine on cuda:{self.device}")
+            if x.dim() != 2:
+                raise ValueError("expected a (W, N) batch of windows")
+            x = x.contiguous()
+            code = {torch.float64: _ffi.PH_F64, torch.float32: _ffi.PH_F32}.get(x.dtype)
+            if code is None:
+                raise TypeError(f"unsupported dtype {x.dtype}")
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            if stream != self._bound_stream:
+                _ffi.check(self._lib.ph_set_stream(self._ctx, C.c_void_p(stream)))
+                self._bound_stream = stream
+            return x, code, x.shape[0], x.shape[1], _ffi.PH_FLAG_DEVICE, _Out(x)
+        x = np.asarray(x)
+        if x.ndim != 2:
+            raise ValueError("expected a (W, N) batch of windows")
+        if x.dtype not in _NP_DTYPES:
+            x = x.astype(np.float64)
+        x = np.ascontiguousarray(x)
+        if self._bound_stream is not None:
+            _ffi.check(self._lib.ph_set_stream(self._ctx, None))
+            self._bound_stream = None
+        return x, _NP_DTYPES[x.dtype], x.shape[0], x.shape[1], 0, _Out(x)
+
+    @staticmethod
+    def _np_dtype(code):
+        return np.float64 if code == _ffi.PH_F64 else np.float32
+
+    @staticmethod
+    def _flags(trunc, orth):
+        return (_ffi.PH_FLAG_TRUNC if trunc else 0) | (_ffi.PH_FLAG_ORTH if orth else 0)
+
+    @staticmethod
+    def _orth(orth, max_p):
+        if not orth:
+            return None, None, None, None, 0
+        off, q = _factors.orth_tables(int(max_p))
+        return off, q, off.ctypes.data, q.ctypes.data, int(max_p)
+
+    def sync(self):
+        _ffi.check(self._lib.ph_sync(self._ctx))
+
+    def timer_begin(self):
+        _ffi.check(self._lib.ph_timer_begin(self._ctx))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0)
+        _ffi.check(self._lib.ph_timer_end(self._ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def max_window(self, dtype=np.float64, trunc=False, orth=False) -> int:
+        n = C.c_int(0)
+        code = _NP_DTYPES[np.dtype(dtype)]
+        _ffi.check(self._lib.ph_max_window(self._ctx, code, self._flags(trunc, orth), C.byref(n)))
+        return n.value
+
+    # ------------------------------------------------------------------ kernels
+    def periodic_norm(self, x, p=None):
+        x, code, W, N, fl, mk = self._prep(x)
+        out = mk.empty((W,), np.float64)
+        with self._lock:
+            _ffi.check(self._lib.ph_periodic_norm(self._ctx, mk.addr(x), code, W, N, int(p) if p else 0, fl, mk.addr(out)))
+        return out
+
+    def project_batch(self, x, p_list, trunc=False, orth=False, single=False):
+        """out[w, k, :] = project(x[w], p_list[k]); Periods.py:142-219."""
+        x, code, W, N, fl, mk = self._prep(x)
+        pl, pl_addr = _i32(np.atleast_1d(p_list))
+        if pl.size < 1 or pl.min() < 1:
+            raise ValueError("periods must be >= 1")
+        keep = self._orth(orth, pl.max())
+        out = mk.empty((W, pl.size, N), self._np_dtype(code))
+        flags = fl | self._flags(trunc, orth) | (_ffi.PH_FLAG_SINGLE if single else 0)
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_project_batch(self._ctx, mk.addr(x), code, W, N, pl_addr, pl.size, keep[2], keep[3], keep[4], flags, mk.addr(out))
+            )
+        return out
+
+    def sweep(self, x, p_lo, p_hi, mode=_ffi.PH_SWEEP_NORM, trunc=False, orth=False):
+        """(W, p_hi-p_lo+1) float64 sweep values; Periods.py:501-510 / :324-331."""
+        x, code, W, N, fl, mk = self._prep(x)
+        keep = self._orth(orth and mode != _ffi.PH_SWEEP_MAXABS, p_hi)
+        out = mk.empty((W, int(p_hi) - int(p_lo) + 1), np.float64)
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_sweep(self._ctx, mk.addr(x), code, W, N, int(p_lo), int(p_hi), int(mode), keep[2], keep[3], keep[4], fl | self._flags(trunc, orth), mk.addr(out))
+            )
+        return out
+
+    def m_best(self, x, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False):
+        """-> periods (W,num) uint32, powers (W,num) f64, bases (W,num,N), status (W) int32."""
+        x, code, W, N, fl, mk = self._prep(x)
+        if max_length is None:
+            max_length = N // 3
+        max_length, min_length, num = int(max_length), int(min_length), int(num)
+        keep = self._orth(orth, max_length)
+        foff, fq = _factors.factor_tables(max(max_length, 1))
+        periods = mk.empty((W, num), np.uint32)
+        powers = mk.empty((W, num), np.float64)
+        bases = mk.empty((W, num, N), self._np_dtype(code))
+        status = mk.empty((W,), np.int32)
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_m_best(
+                    self._ctx, mk.addr(x), code, W, N, num, min_length, max_length, 1 if gamma else 0,
+                    keep[2], keep[3], foff.ctypes.data, fq.ctypes.data, max(max_length, 1),
+                    fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status),
+                )
+            )
+        return periods, powers, bases, status
+
+    def small_to_large(self, x, thresh=0.1, n_periods=None, trunc=False, orth=False, cap=16, want_bases=True):
+        """-> counts (W), periods (W,cap) int32, powers (W,cap), bases (W,cap,N)|None, status (W).
+        Host-pointer calls grow `cap` and retry when a window accepts more periods."""
+        x, code, W, N, fl, mk = self._prep(x)
+        if n_periods is None:
+            n_periods = N // 2
+        n_periods = int(n_periods)
+        keep = self._orth(orth, max(n_periods, 1))
+        while True:
+            counts = mk.empty((W,), np.int32)
+            periods = mk.empty((W, cap), np.int32)
+            powers = mk.empty((W, cap), np.float64)
+            bases = mk.empty((W, cap, N), self._np_dtype(code)) if want_bases else None
+            status = mk.empty((W,), np.int32)
+            with self._lock:
+                rc = self._lib.ph_small_to_large(
+                    self._ctx, mk.addr(x), code, W, N, float(thresh), n_periods, keep[2], keep[3], keep[4],
+                    fl | self._flags(trunc, orth), int(cap), mk.addr(counts), mk.addr(periods), mk.addr(powers),
+                    mk.addr(bases), mk.addr(status),
+                )
+            if rc == _ffi.PH_E_CAP and not mk.torch:
+                cap = int(counts.max())
+                continue
+            _ffi.check(rc)
+            return counts, periods, powers, bases, status
+
+    def best_correlation(self, x, num=5, max_length=None, ratio=0.01, trunc=False, orth=False):
+        x, code, W, N, fl, mk = self._prep(x)
+        if max_length is None:
+            max_length = N // 3
+        max_length, num = int(max_length), int(num)
+        keep = self._orth(orth, max(max_length, 1))
+        periods = mk.empty((W, num), np.uint32)
+        norms = mk.empty((W, num), np.float64)
+        bases = mk.empty((W, num, N), self._np_dtype(code))
+        status = mk.empty((W,), np.int32)
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_best_correlation(
+                    self._ctx, mk.addr(x), code, W, N, num, max_length, float(ratio), keep[2], keep[3], keep[4],
+                    fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(norms), mk.addr(bases), mk.addr(status),
+                )
+            )
+        return periods, norms, bases, status
+
+    def ramanujan_norms(self, x, q_lo=2, q_hi=None):
+        """(W, q_hi+1) float64; RamanujanPeriods.py:67-86."""
+        x, code, W, N, fl, mk = self._prep(x)
+        if not q_hi:
+            q_hi = N // 3
+        out = mk.empty((W, int(q_hi) + 1), np.float64)
+        with self._lock:
+            _ffi.check(self._lib.ph_ramanujan_norms(self._ctx, mk.addr(x), code, W, N, int(q_lo), int(q_hi), fl, mk.addr(out)))
+        return out
+
+    def dict_project(self, x, basis):
+        """RamanujanPeriods.project(x, basis) for an arbitrary dictionary (numpy only)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        basis = np.ascontiguousarray(basis, dtype=np.float64)
+        if x.ndim != 1 or basis.ndim != 2 or basis.shape[1] != x.size:
+            raise ValueError("x must be (N,) and basis (rows, N)")
+        out = np.empty(basis.shape, dtype=np.float32)
+        with self._lock:
+            if self._bound_stream is not None:
+                _ffi.check(self._lib.ph_set_stream(self._ctx, None))
+                self._bound_stream = None
+            _ffi.check(self._lib.ph_dict_project(self._ctx, x.ctypes.data, basis.ctypes.data, basis.shape[0], x.size, 0, out.ctypes.data))
+        return out
+
+    def fold_sums(self, x, p_list, keep):
+        """W = A x for natural-basis rows (QOPeriods.py:782): (W, sum(keep)) float64."""
+        x, code, W, N, fl, mk = self._prep(x)
+        pl, pl_addr = _i32(np.atleast_1d(p_list))
+        kp, kp_addr = _i32(np.atleast_1d(keep))
+        out = mk.empty((W, int(kp.sum())), np.float64)
+        with self._lock:
+            _ffi.check(self._lib.ph_fold_sums(self._ctx, mk.addr(x), code, W, N, pl_addr, kp_addr, pl.size, fl, mk.addr(out)))
+        return out
+
+    def tile_sum(self, wts, n, p_list, keep, dtype=np.float64):
+        """Reconstruction A^T w (QOPeriods.py:795): (W, n)."""
+        wts2, code, W, S, fl, mk = self._prep(wts)
+        if code != _ffi.PH_F64:
+            raise TypeError("weights must be float64")
+        pl, pl_addr = _i32(np.atleast_1d(p_list))
+        kp, kp_addr = _i32(np.atleast_1d(keep))
+        if int(kp.sum()) != S:
+            raise ValueError("weights row length must equal sum(keep)")
+        ocode = _NP_DTYPES[np.dtype(dtype)]
+        out = mk.empty((W, int(n)), self._np_dtype(ocode))
+        with self._lock:
+            _ffi.check(self._lib.ph_tile_sum(self._ctx, mk.addr(wts2), W, int(n), pl_addr, kp_addr, pl.size, ocode, fl, mk.addr(out)))
+        return out
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_engine() -> PeriodEngine:
+    """Process-wide engine on cuda:LOCAL_RANK (one process per GPU)."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = PeriodEngine()
+        return _default

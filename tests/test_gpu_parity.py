@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes engine) against the CPU oracle
+on the same seeded inputs, against the committed golden vectors from the reference, and --
+at BASELINE.json's full sizes -- through size-independent properties.
+
+Bars (BASELINE.json): integer period lists bit-exact; fp64 powers / bases / norms within
+1e-10 relative; Periods.project (non-orth) bit-identical; Ramanujan norms within 1e-5
+relative (the reference accumulates in float32, RamanujanPeriods.py:127).
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import period_oracle as po
+from pyperiod_amd.synth import multi_sinusoid_batch, multi_sinusoid_window, readme_window
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+FLAGS = [(False, False), (True, False), (False, True), (True, True)]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import default_engine
+
+    return default_engine()
+
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
+# ------------------------------------------------------------------------------ K1 project
+def test_project_matches_reference_golden(eng, golden):
+    g = golden("project")
+    for n in (10, 97, 240, 4096):
+        x = g[f"x_{n}"]
+        plist = [p for p in (2, 3, 7, 12, 64, 97, n // 2) if 2 <= p <= n]
+        for trunc, orth in FLAGS:
+            out = eng.project_batch(x[None, :], plist, trunc, orth)[0]
+            for k, p in enumerate(plist):
+                key = f"n{n}_p{p}_t{int(trunc)}_o{int(orth)}"
+                want = g[key] if n <= 240 else np.tile(g[key + "_single"], n // p + 1)[:n]
+                assert np.array_equal(out[k], want), key  # bit-identical, all four modes
+
+
+def test_project_batch_bit_exact_vs_oracle(eng):
+    n = 1000
+    x = multi_sinusoid_batch(20, 5, n)
+    plist = list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 333, 499, 500, 501, 999, 1000]
+    for trunc, orth in FLAGS:
+        out = eng.project_batch(x, plist, trunc, orth)
+        for w in range(x.shape[0]):
+            for k, p in enumerate(plist):
+                want = po.project(x[w], p, trunc, orth)
+                if p == 1:
+                    # a (N, 1) rectangle reduces along its contiguous axis, where numpy sums
+                    # pairwise; p = 1 (the mean) is never part of a sweep
+                    assert rel_err(out[w, k], want) < 1e-12
+                else:
+                    assert np.array_equal(out[w, k], want, equal_nan=True), (trunc, orth, w, p)
+    single = eng.project_batch(x, plist, False, False, single=True)
+    for k, p in enumerate(plist):
+        assert np.array_equal(single[:, k, :p], eng.project_batch(x, [p])[:, 0, :p])
+        assert not single[:, k, p:].any()
+
+
+def test_project_period_longer_than_window(eng):
+    x = multi_sinusoid_window(3, 50)
+    out = eng.project_batch(x[None, :], [64, 51, 50, 49])[0]
+    for k, p in enumerate([64, 51, 50, 49]):
+        assert np.array_equal(out[k], po.project(x, p), equal_nan=True)
+    t = eng.project_batch(x[None, :], [64], True, False)[0, 0]
+    assert np.isnan(t).all()  # np.mean over zero complete rows (Periods.py:182-184)
+
+
+def test_project_float32_window(eng):
+    x = multi_sinusoid_batch(0, 3, 512, dtype=np.float32)
+    out = eng.project_batch(x, [7, 64, 100])
+    assert out.dtype == np.float32
+    for w in range(3):
+        for k, p in enumerate([7, 64, 100]):
+            assert rel_err(out[w, k], po.project(x[w].astype(np.float64), p)) < 1e-5
+
+
+def test_periodic_norm(eng):
+    x = multi_sinusoid_batch(5, 4, 777)
+    got = eng.periodic_norm(x)
+    for w in range(4):
+        assert abs(got[w] - po.periodic_norm(x[w])) <= 1e-14 * got[w]
+    got = eng.periodic_norm(x, 9)
+    for w in range(4):
+        assert abs(got[w] - po.periodic_norm(x[w], 9)) <= 1e-14 * got[w]
+    assert abs(eng.periodic_norm(np.arange(10.0)[None, :])[0] - 5.338539126015656) < 1e-14
+
+
+# ------------------------------------------------------------------------------ K2 sweep
+def test_sweep_matches_reference_golden(eng, golden):
+    from pyperiod_amd import _ffi
+
+    g = golden("sweep")
+    n = 4096
+    x = multi_sinusoid_batch(0, 4, n)
+    plain = eng.sweep(x, 2, n // 3, _ffi.PH_SWEEP_NORM)
+    gamma = eng.sweep(x, 2, n // 3, _ffi.PH_SWEEP_NORM_GAMMA)
+    for w in range(4):
+        assert rel_err(plain[w], g[f"plain_w{w}"]) < TOL
+        assert rel_err(gamma[w], g[f"gamma_w{w}"]) < TOL
+    maxabs = eng.sweep(x[:1], 2, n // 3, _ffi.PH_SWEEP_MAXABS)[0]
+    assert np.array_equal(maxabs, g["maxabs_w0"])  # row-order sums: bit-identical
+    for trunc, orth in FLAGS[1:]:
+        got = eng.sweep(x[:1], 2, n // 3, _ffi.PH_SWEEP_NORM, trunc, orth)[0]
+        assert rel_err(got, g[f"plain_w0_t{int(trunc)}_o{int(orth)}"]) < TOL
+
+
+def test_sweep_ragged_sizes_vs_oracle(eng):
+    from pyperiod_amd import _ffi
+
+    for n, p_lo, p_hi in ((97, 1, 97), (1000, 2, 500), (130, 60, 140)):
+        x = multi_sinusoid_batch(9, 3, n)
+        got = eng.sweep(x, p_lo, p_hi, _ffi.PH_SWEEP_NORM)
+        gam = eng.sweep(x, p_lo, p_hi, _ffi.PH_SWEEP_NORM_GAMMA)
+        mab = eng.sweep(x, p_lo, p_hi, _ffi.PH_SWEEP_MAXABS)
+        for w in range(3):
+            assert rel_err(got[w], po.sweep_norms(x[w], p_lo, p_hi)) < TOL
+            assert rel_err(gam[w], po.sweep_norms(x[w], p_lo, p_hi, gamma=True)) < TOL
+            want = po.sweep_maxabs(x[w], p_lo, p_hi)
+            lo = 1 if p_lo == 1 else 0  # p = 1: numpy sums the contiguous axis pairwise
+            assert np.array_equal(mab[w, lo:], want[lo:])
+            assert rel_err(mab[w, :lo], want[:lo]) < 1e-13
+
+
+# ------------------------------------------------------------------------------ m_best
+@pytest.mark.parametrize("name,gamma", [("m_best", False), ("m_best_gamma", True)])
+def test_m_best_matches_reference_golden(eng, golden, name, gamma):
+    g = golden("m_best")
+    x = multi_sinusoid_batch(0, 4, 4096)
+    per, pw, bs, st = eng.m_best(x, 10, None, 2, gamma)
+    assert per.dtype == np.uint32 and not st.any()
+    for w in range(4):
+        assert np.array_equal(per[w], g[f"{name}_w{w}_periods"]), w
+        assert rel_err(pw[w], g[f"{name}_w{w}_powers"]) < TOL
+    assert rel_err(bs[1], g[f"{name}_w1_bases"]) < TOL
+    x = multi_sinusoid_batch(4, 2, 1500)
+    per, pw, bs, st = eng.m_best(x, 6, 300, 3, gamma)
+    for k, w in enumerate((4, 5)):
+        assert np.array_equal(per[k], g[f"{name}_n1500_w{w}_periods"])
+        assert rel_err(pw[k], g[f"{name}_n1500_w{w}_powers"]) < TOL
+        assert rel_err(bs[k], g[f"{name}_n1500_w{w}_bases"]) < TOL
+    per, pw, bs, st = eng.m_best(readme_window(2000, 0)[None, :], 10, None, 2, gamma)
+    assert np.array_equal(per[0], g[f"{name}_c1_periods"])
+    assert rel_err(pw[0], g[f"{name}_c1_powers"]) < TOL and rel_err(bs[0], g[f"{name}_c1_bases"]) < TOL
+    for trunc, orth in FLAGS[1:]:
+        tag = f"{name}_n900_t{int(trunc)}_o{int(orth)}"
+        per, pw, bs, st = eng.m_best(multi_sinusoid_window(6, 900)[None, :], 5, None, 2, gamma, trunc, orth)
+        assert np.array_equal(per[0], g[tag + "_periods"]), tag
+        assert rel_err(pw[0], g[tag + "_powers"]) < TOL and rel_err(bs[0], g[tag + "_bases"]) < TOL
+
+
+def test_m_best_batch_vs_oracle(eng):
+    x = multi_sinusoid_batch(40, 6, 768)
+    for gamma in (False, True):
+        per, pw, bs, st = eng.m_best(x, 5, None, 2, gamma)
+        for w in range(6):
+            rper, rpw, rbs = po.m_best(x[w], 5, gamma=gamma)
+            assert np.array_equal(per[w], rper), (gamma, w)
+            assert rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL
+
+
+def test_m_best_zero_window_reports_status(eng):
+    from pyperiod_amd import Periods, _ffi
+
+    x = np.zeros((2, 256))
+    x[1] = multi_sinusoid_window(0, 256)
+    per, pw, bs, st = eng.m_best(x, 3)
+    assert st[0] == _ffi.PH_ST_NO_PERIOD and st[1] == 0
+    with pytest.raises(TypeError):  # the reference raises UFuncTypeError (a TypeError) at Periods.py:520
+        Periods().m_best(np.zeros(256), num=3)
+
+
+# ------------------------------------------------------------------------------ small_to_large
+def test_small_to_large_matches_reference_golden(eng, golden):
+    from pyperiod_amd import Periods
+
+    g = golden("small_to_large")
+    per, pw, bs = Periods().small_to_large(readme_window(2000, 0), thresh=0.1)  # BASELINE config 1
+    assert per == list(g["c1_periods"]) and all(isinstance(v, int) for v in per)
+    assert rel_err(pw, g["c1_powers"]) < TOL and rel_err(np.array(bs), g["c1_bases"]) < TOL
+    x = multi_sinusoid_batch(0, 4, 4096)
+    counts, per, pw, bs, st = eng.small_to_large(x, 0.05)  # config 4 unit
+    for w in range(4):
+        k = counts[w]
+        assert list(per[w, :k]) == list(g[f"w{w}_periods"]), w
+        assert rel_err(pw[w, :k], g[f"w{w}_powers"]) < TOL
+    assert rel_err(bs[1, : counts[1]], g["w1_bases"]) < TOL
+    for trunc, orth in FLAGS[1:]:
+        tag = f"n1200_t{int(trunc)}_o{int(orth)}"
+        per, pw, bs = Periods(trunc, orth).small_to_large(multi_sinusoid_window(2, 1200), thresh=0.05)
+        assert per == list(g[tag + "_periods"]), tag
+        assert rel_err(pw, g[tag + "_powers"]) < TOL
+        assert rel_err(np.array(bs).reshape(len(per), 1200), g[tag + "_bases"]) < TOL
+    per, pw, _ = Periods().small_to_large(multi_sinusoid_window(3, 600), thresh=0.02, n_periods=100)
+    assert per == list(g["n600_np100_periods"]) and rel_err(pw, g["n600_np100_powers"]) < TOL
+
+
+def test_small_to_large_cap_retry_and_empty(eng):
+    x = multi_sinusoid_batch(60, 3, 500)
+    counts, per, pw, bs, st = eng.small_to_large(x, 0.001, cap=2)  # low threshold: many accepts
+    for w in range(3):
+        rper, rpw, rbs = po.small_to_large(x[w], 0.001)
+        assert counts[w] == len(rper) and list(per[w, : counts[w]]) == rper
+        assert rel_err(pw[w, : counts[w]], rpw) < TOL
+        assert rel_err(bs[w, : counts[w]], np.array(rbs)) < TOL
+    counts, per, pw, bs, st = eng.small_to_large(x, 10.0)  # nothing can pass
+    assert not counts.any()
+
+
+# ------------------------------------------------------------------------------ best_correlation
+def test_best_correlation_matches_reference_golden(eng, golden):
+    g = golden("best_correlation")
+    x = multi_sinusoid_batch(2, 2, 700)
+    per, nr, bs, st = eng.best_correlation(x, 5, None, 0.01)
+    for k, w in enumerate((2, 3)):
+        assert np.array_equal(per[k], g[f"bc_n700_w{w}_periods"])
+        assert rel_err(nr[k], g[f"bc_n700_w{w}_norms"]) < TOL
+        assert rel_err(bs[k], g[f"bc_n700_w{w}_bases"]) < TOL
+    per, nr, bs, st = eng.best_correlation(multi_sinusoid_window(1, 4096)[None, :], 3)
+    assert np.array_equal(per[0], g["bc_n4096_periods"])
+    assert rel_err(nr[0], g["bc_n4096_norms"]) < TOL and rel_err(bs[0], g["bc_n4096_bases"]) < TOL
+
+
+def test_best_frequency_matches_reference_golden(eng, golden):
+    from pyperiod_amd import Periods
+
+    g = golden("best_correlation")
+    per, pw, bs = Periods().best_frequency(readme_window(2000, 0), None, 4)
+    assert np.array_equal(per, g["bf_c1_periods"])
+    assert rel_err(pw, g["bf_c1_powers"]) < TOL and rel_err(bs, g["bf_c1_bases"]) < TOL
+
+
+# ------------------------------------------------------------------------------ Ramanujan
+def test_ramanujan_matches_reference_golden(eng, golden):
+    from pyperiod_amd import RamanujanPeriods
+
+    g = golden("ramanujan")
+    rp = RamanujanPeriods()
+    got = rp.find_periods(multi_sinusoid_window(0, 240), 2, 80)
+    assert got.shape == (81,) and got[0] == 0 and got[1] == 0
+    assert rel_err(got, g["norms_n240"]) < 1e-5
+    assert rel_err(got, po.ramanujan_norms_folded(multi_sinusoid_window(0, 240), 2, 80)) < TOL
+    got = rp.find_periods(multi_sinusoid_window(1, 8192), 2, 64)
+    assert rel_err(got, g["norms_n8192_pmax64"]) < 1e-5
+    got = rp.find_periods(multi_sinusoid_window(2, 1000))
+    assert got.shape == g["norms_n1000_default"].shape and rel_err(got, g["norms_n1000_default"]) < 1e-5
+    x = multi_sinusoid_window(0, 240)
+    basis = rp.Cq_complete(12, 240)
+    proj = RamanujanPeriods.project(x, basis)
+    assert proj.dtype == np.float32 and rel_err(proj, po.ramanujan_project(x, basis)) < 1e-6
+
+
+# ------------------------------------------------------------------------------ QOPeriods
+def test_qoperiods_matches_reference_golden(eng, golden):
+    from pyperiod_amd import QOPeriods
+
+    g = golden("qoperiods")
+    qo = QOPeriods()
+    a, d = qo.get_subspaces([12, 18, 8, 5], 1024)
+    assert list(d.values()) == list(g["dims_12_18_8_5_vals"])
+    w, rec = qo._solve_structured(g["solve_x"], a, d)
+    assert rel_err(w, g["solve_w"]) < 1e-9 and rel_err(rec, g["solve_recon"]) < 1e-9
+    w2, rec2 = QOPeriods.solve_quadratic(g["solve_x"], a)
+    assert rel_err(w2, g["solve_w"]) < 1e-8 and rel_err(rec2, g["solve_recon"]) < 1e-8
+    for tag, sig, kw in (
+        ("c1", readme_window(2000, 0), dict(num=2, thresh=0.05)),
+        ("w5", multi_sinusoid_window(5, 1536), dict(num=4, thresh=0.2, min_length=4, max_length=200)),
+    ):
+        out, res = qo.find_periods(sig, **kw)
+        assert np.array_equal(out["periods"], g[f"fp_{tag}_periods"]), tag
+        assert rel_err(out["norms"], g[f"fp_{tag}_norms"]) < TOL
+        assert [int(k) for k in out["basis_dictionary"]] == list(g[f"fp_{tag}_dict_keys"])
+        assert list(out["basis_dictionary"].values()) == list(g[f"fp_{tag}_dict_vals"])
+        assert rel_err(out["weights"], g[f"fp_{tag}_weights"]) < 1e-8
+        assert rel_err(res, g[f"fp_{tag}_residual"]) < 1e-8
+
+
+# ------------------------------------------------------------------------------ class surface
+def test_class_surface_matches_reference_behaviour(eng):
+    from pyperiod_amd import Periods
+
+    assert np.array_equal(Periods.project(np.arange(10.0), 3), [4.5, 4, 5, 4.5, 4, 5, 4.5, 4, 5, 4.5])
+    assert np.array_equal(Periods.project(np.arange(10.0), 3, True), [3, 4, 5, 3, 4, 5, 3, 4, 5, 3])
+    assert np.array_equal(Periods.project(np.arange(10.0), 3, return_single_period=True), [4.5, 4, 5])
+    assert abs(Periods.periodic_norm(np.arange(10.0)) - 5.338539126015656) < 1e-14
+    assert abs(Periods.periodic_norm(np.arange(10.0), 3) - 3.0822070014844885) < 1e-14
+    with pytest.raises(AttributeError):  # list input, Periods.py:171
+        Periods.project([1.0, 2.0, 3.0], 2)
+    with pytest.raises(ValueError):  # 2-D input, Periods.py:176
+        Periods.project(np.zeros((2, 8)), 2)
+    x = multi_sinusoid_window(0, 64)
+    keep = x.copy()
+    Periods.project(x, 5, False, True)
+    assert np.array_equal(x, keep)  # inputs are never mutated
+    p = Periods(True, False)
+    assert p.trunc_to_integer_multiple == (True, False)  # tuple quirk, Periods.py:610-611
+    with pytest.warns(UserWarning):
+        Periods(False, True).m_best(multi_sinusoid_window(1, 300), num=2)
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_config2_full_size_properties(eng):
+    """BASELINE config 2 shape (1024 windows x N=4096, m_best num=10): properties that do not
+    need the oracle at full size, plus oracle spot checks on a few windows."""
+    from pyperiod_amd import _ffi
+
+    W, n, num = 1024, 4096, 10
+    x = multi_sinusoid_batch(0, W, n)
+    per, pw, bs, st = eng.m_best(x, num)
+    assert not st.any()
+    assert per.min() >= 2 and per.max() <= n // 3
+    # every basis row is exactly periodic with its own period (tile structure)
+    for w in (0, 17, 511, 1023):
+        for k in range(num):
+            p = int(per[w, k])
+            assert np.array_equal(bs[w, k, p:], bs[w, k, :-p]), (w, k)
+    # the batch result equals the per-window result (windows are independent)
+    for w in (5, 900):
+        p1, w1, b1, _ = eng.m_best(x[w : w + 1], num)
+        assert np.array_equal(p1[0], per[w]) and np.array_equal(w1[0], pw[w]) and np.array_equal(b1[0], bs[w])
+    # oracle spot check on two windows of the full batch
+    for w in (2, 3):
+        rper, rpw, rbs = po.m_best(x[w], num)
+        assert np.array_equal(per[w], rper) and rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL
+    # sweep: linearity in scale and Bessel's inequality ||P_p x|| <= ||x||
+    sw = eng.sweep(x, 2, n // 3, _ffi.PH_SWEEP_NORM)
+    nx = eng.periodic_norm(x)
+    assert np.all(sw <= nx[:, None] * (1 + 1e-12))
+    sw2 = eng.sweep(2.0 * x[:64], 2, n // 3, _ffi.PH_SWEEP_NORM)
+    assert np.array_equal(sw2, 2.0 * sw[:64])  # power-of-two scaling is exact in binary fp
+    # idempotence of the projection
+    pl = [37, 64, 1365]
+    pr = eng.project_batch(x[:8], pl)
+    for k, p in enumerate(pl):
+        again = eng.project_batch(pr[:, k, :].copy(), [p])[:, 0, :]
+        assert rel_err(again, pr[:, k, :]) < 1e-14
