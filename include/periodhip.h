@@ -85,6 +85,13 @@ int ph_sync(ph_ctx* ctx);
 /* HIP-event timer on the context's stream (the stream the kernels run on). */
 int ph_timer_begin(ph_ctx* ctx);
 int ph_timer_end(ph_ctx* ctx, float* elapsed_ms);
+/* Per-kernel timing: while enabled, every kernel the library launches on this context is
+ * bracketed with HIP events on the context's stream (up to 256 launches since the last
+ * ph_profile_enable).  ph_profile_read synchronises the stream and returns the elapsed
+ * milliseconds of launch i in ms[i]; ph_profile_name gives the kernel's name. */
+int ph_profile_enable(ph_ctx* ctx, int on);
+int ph_profile_read(ph_ctx* ctx, float* ms, int cap, int* count);
+const char* ph_profile_name(ph_ctx* ctx, int i);
 /* Multiprocessor count and per-workgroup LDS limit of the context's device. */
 int ph_device_info(ph_ctx* ctx, int* num_cu, int* lds_bytes);
 /* Largest N the window-resident kernels accept for `dtype` with `flags`. */
@@ -123,7 +130,8 @@ int ph_m_best(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int num,
               int min_length, int max_length, int gamma,
               const int32_t* orth_off, const int32_t* orth_q,
               const int32_t* fac_off, const int32_t* fac_q, int table_max_p,
-              unsigned flags, uint32_t* periods, double* powers, void* bases, int32_t* status);
+              unsigned flags, uint32_t* periods, double* powers, void* bases, int32_t* status,
+              int32_t* n_sweeps /* (W) all-p sweeps each window needed in step 1, or NULL */);
 
 /* ---- Periods.small_to_large (Periods.py:246-287) ----------------------------------------
  * counts (W) int32 = number of accepted periods; periods (W, cap) int32; powers (W, cap)

@@ -38,7 +38,9 @@ SIGNATURES = {
     "ph_periodic_norm": [_vp, _vp, _i, _i64, _i, _i, _u, _vp],
     "ph_project_batch": [_vp, _vp, _i, _i64, _i, _pi32, _i, _pi32, _pi32, _i, _u, _vp],
     "ph_sweep": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _pi32, _pi32, _i, _u, _vp],
-    "ph_m_best": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _pi32, _pi32, _pi32, _pi32, _i, _u, _vp, _vp, _vp, _vp],
+    "ph_m_best": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _pi32, _pi32, _pi32, _pi32, _i, _u, _vp, _vp, _vp, _vp, _vp],
+    "ph_profile_enable": [_vp, _i],
+    "ph_profile_read": [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)],
     "ph_small_to_large": [_vp, _vp, _i, _i64, _i, _d, _i, _pi32, _pi32, _i, _u, _i, _vp, _vp, _vp, _vp, _vp],
     "ph_best_correlation": [_vp, _vp, _i, _i64, _i, _i, _i, _d, _pi32, _pi32, _i, _u, _vp, _vp, _vp, _vp],
     "ph_ramanujan_norms": [_vp, _vp, _i, _i64, _i, _i, _i, _u, _vp],
@@ -101,6 +103,8 @@ def load():
         fn.restype = _i
     lib.ph_last_error.argtypes = []
     lib.ph_last_error.restype = C.c_char_p
+    lib.ph_profile_name.argtypes = [_vp, _i]
+    lib.ph_profile_name.restype = C.c_char_p
     _lib = lib
     return lib
 

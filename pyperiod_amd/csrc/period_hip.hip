@@ -66,6 +66,11 @@ struct ph_ctx {
   int lds_limit = 0;
   DevBuf buf[B_COUNT];
   TableSlot tab[T_COUNT];
+  // optional per-kernel HIP-event timing (ph_profile_*)
+  bool prof_on = false;
+  int prof_n = 0;
+  std::vector<hipEvent_t> prof_ev;  // 2 events per recorded launch
+  std::vector<const char*> prof_name;
 };
 
 namespace {
@@ -135,6 +140,34 @@ int allow_lds(K kernel, size_t bytes) {
   }
   return PH_OK;
 }
+
+constexpr int kProfCap = 256;
+
+// Brackets one kernel launch with HIP events on the context's stream when profiling is on.
+struct ProfScope {
+  ph_ctx* c;
+  bool live;
+  ProfScope(ph_ctx* ctx, const char* name) : c(ctx), live(ctx->prof_on && ctx->prof_n < kProfCap) {
+    if (!live) return;
+    if ((int)c->prof_ev.size() < 2 * (c->prof_n + 1)) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        live = false;
+        return;
+      }
+      c->prof_ev.push_back(a);
+      c->prof_ev.push_back(b);
+      c->prof_name.push_back(name);
+    }
+    c->prof_name[c->prof_n] = name;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream);
+  }
+  ~ProfScope() {
+    if (!live) return;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream);
+    c->prof_n += 1;
+  }
+};
 
 int launch_check(const char* what) {
   hipError_t e = hipGetLastError();
@@ -295,6 +328,7 @@ int ph_destroy(ph_ctx* c) {
     if (b.p) (void)hipFree(b.p);
   for (TableSlot& t : c->tab)
     if (t.dev.p) (void)hipFree(t.dev.p);
+  for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -327,6 +361,27 @@ int ph_timer_end(ph_ctx* c, float* ms) {
   PH_HIP(hipEventSynchronize(c->ev1));
   PH_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
   return PH_OK;
+}
+
+int ph_profile_enable(ph_ctx* c, int on) {
+  if (!c) return fail(PH_E_ARG, "ctx is NULL");
+  c->prof_on = on != 0;
+  c->prof_n = 0;
+  return PH_OK;
+}
+
+int ph_profile_read(ph_ctx* c, float* ms, int cap, int* count) {
+  if (!c || !count) return fail(PH_E_ARG, "NULL argument");
+  PH_HIP(hipStreamSynchronize(c->stream));
+  *count = c->prof_n;
+  for (int i = 0; i < c->prof_n && i < cap && ms; ++i)
+    PH_HIP(hipEventElapsedTime(&ms[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+  return PH_OK;
+}
+
+const char* ph_profile_name(ph_ctx* c, int i) {
+  if (!c || i < 0 || i >= c->prof_n) return "";
+  return c->prof_name[i];
 }
 
 int ph_device_info(ph_ctx* c, int* num_cu, int* lds_bytes) {
@@ -376,12 +431,18 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
   const dim3 grid((unsigned)(W * chunks));
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_project_batch<double>, lds));
-    hipLaunchKernelGGL(ph::k_project_batch<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                       d_plist, n_p, chunks, kflags, tb, (double*)dout);
+    {
+      ProfScope ps_(c, "k_project_batch");
+      hipLaunchKernelGGL(ph::k_project_batch<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
+                         d_plist, n_p, chunks, kflags, tb, (double*)dout);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_project_batch<float>, lds));
-    hipLaunchKernelGGL(ph::k_project_batch<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                       d_plist, n_p, chunks, kflags, tb, (float*)dout);
+    {
+      ProfScope ps_(c, "k_project_batch");
+      hipLaunchKernelGGL(ph::k_project_batch<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
+                         d_plist, n_p, chunks, kflags, tb, (float*)dout);
+    }
   }
   PH_TRY(launch_check("k_project_batch"));
   return st.finish();
@@ -412,12 +473,18 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   const dim3 grid((unsigned)(W * chunks));
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_sweep<double>, lds));
-    hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, p_lo,
-                       p_hi, mode, chunks, kflags, tb, (double*)dout);
+    {
+      ProfScope ps_(c, "k_sweep");
+      hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, p_lo,
+                         p_hi, mode, chunks, kflags, tb, (double*)dout);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_sweep<float>, lds));
-    hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
-                       mode, chunks, kflags, tb, (double*)dout);
+    {
+      ProfScope ps_(c, "k_sweep");
+      hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
+                         mode, chunks, kflags, tb, (double*)dout);
+    }
   }
   PH_TRY(launch_check("k_sweep"));
   return st.finish();
@@ -427,7 +494,7 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
 int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, int min_length, int max_length,
               int gamma, const int32_t* orth_off, const int32_t* orth_q, const int32_t* fac_off,
               const int32_t* fac_q, int table_max_p, unsigned flags, uint32_t* periods, double* powers,
-              void* bases, int32_t* status) {
+              void* bases, int32_t* status, int32_t* n_sweeps) {
   PH_TRY(check_common(c, x, dtype, W, N));
   if (!periods || !powers || !bases || !status) return fail(PH_E_ARG, "output pointer is NULL");
   if (num < 1 || num > 4096) return fail(PH_E_ARG, "num=%d must be in [1, 4096]", num);
@@ -454,6 +521,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   PH_TRY(st.out(B_OUT1, powers, (size_t)W * num * sizeof(double), &dpow));
   PH_TRY(st.out(B_OUT2, bases, (size_t)W * num * N * sz, &dbases));
   PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
+  void* dsweeps;
+  PH_TRY(st.out(B_OUT4, n_sweeps, (size_t)W * sizeof(int32_t), &dsweeps));
   PH_TRY(ensure(c, c->buf[B_WS0], (size_t)W * sizeof(double)));
   double* dnorm = static_cast<double*>(c->buf[B_WS0].p);
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
@@ -462,21 +531,33 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_mbest_step1<double>, lds1));
     PH_TRY(allow_lds(ph::k_mbest_step2<double>, lds2));
-    hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(kBlock), lds1, c->stream, (const double*)dx, N, num,
-                       min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
-                       (double*)dbases, dnorm, (int*)dstat);
+    {
+      ProfScope ps_(c, "k_mbest_step1");
+      hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(kBlock), lds1, c->stream, (const double*)dx, N, num,
+                         min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
+                         (double*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
+    }
     PH_TRY(launch_check("k_mbest_step1"));
-    hipLaunchKernelGGL(ph::k_mbest_step2<double>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                       kflags, tb, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
+    {
+      ProfScope ps_(c, "k_mbest_step2");
+      hipLaunchKernelGGL(ph::k_mbest_step2<double>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
+                         kflags, tb, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_mbest_step1<float>, lds1));
     PH_TRY(allow_lds(ph::k_mbest_step2<float>, lds2));
-    hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(kBlock), lds1, c->stream, (const float*)dx, N, num,
-                       min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
-                       (float*)dbases, dnorm, (int*)dstat);
+    {
+      ProfScope ps_(c, "k_mbest_step1");
+      hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(kBlock), lds1, c->stream, (const float*)dx, N, num,
+                         min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
+                         (float*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
+    }
     PH_TRY(launch_check("k_mbest_step1"));
-    hipLaunchKernelGGL(ph::k_mbest_step2<float>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                       kflags, tb, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
+    {
+      ProfScope ps_(c, "k_mbest_step2");
+      hipLaunchKernelGGL(ph::k_mbest_step2<float>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
+                         kflags, tb, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
+    }
   }
   PH_TRY(launch_check("k_mbest_step2"));
   return st.finish();
@@ -513,14 +594,20 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   const dim3 grid((unsigned)W);
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_small_to_large<double>, lds));
-    hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                       thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow,
-                       (double*)dbases, (int*)dstat);
+    {
+      ProfScope ps_(c, "k_small_to_large");
+      hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
+                         thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow,
+                         (double*)dbases, (int*)dstat);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_small_to_large<float>, lds));
-    hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                       thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
-                       (int*)dstat);
+    {
+      ProfScope ps_(c, "k_small_to_large");
+      hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
+                         thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
+                         (int*)dstat);
+    }
   }
   PH_TRY(launch_check("k_small_to_large"));
   PH_TRY(st.finish());
@@ -560,14 +647,20 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   const dim3 grid((unsigned)W);
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_best_correlation<double>, lds));
-    hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                       num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
-                       (int*)dstat);
+    {
+      ProfScope ps_(c, "k_best_correlation");
+      hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
+                         num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
+                         (int*)dstat);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_best_correlation<float>, lds));
-    hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                       num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
-                       (int*)dstat);
+    {
+      ProfScope ps_(c, "k_best_correlation");
+      hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
+                         num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
+                         (int*)dstat);
+    }
   }
   PH_TRY(launch_check("k_best_correlation"));
   return st.finish();
@@ -625,12 +718,18 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   if (q_lo <= q_hi) {
     if (dtype == PH_F64) {
       PH_TRY(allow_lds(ph::k_ramanujan<double>, lds));
-      hipLaunchKernelGGL(ph::k_ramanujan<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, q_lo,
-                         q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+      {
+        ProfScope ps_(c, "k_ramanujan");
+        hipLaunchKernelGGL(ph::k_ramanujan<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, q_lo,
+                           q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+      }
     } else {
       PH_TRY(allow_lds(ph::k_ramanujan<float>, lds));
-      hipLaunchKernelGGL(ph::k_ramanujan<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, q_lo,
-                         q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+      {
+        ProfScope ps_(c, "k_ramanujan");
+        hipLaunchKernelGGL(ph::k_ramanujan<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, q_lo,
+                           q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+      }
     }
     PH_TRY(launch_check("k_ramanujan"));
   }
@@ -674,12 +773,18 @@ int ph_fold_sums(ph_ctx* c, const void* x, int dtype, int64_t W, int N, const in
   const dim3 grid((unsigned)W);
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_fold_sums<double>, lds));
-    hipLaunchKernelGGL(ph::k_fold_sums<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, d_p,
-                       d_keep, d_off, n_p, stride, (double*)dout);
+    {
+      ProfScope ps_(c, "k_fold_sums");
+      hipLaunchKernelGGL(ph::k_fold_sums<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, d_p,
+                         d_keep, d_off, n_p, stride, (double*)dout);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_fold_sums<float>, lds));
-    hipLaunchKernelGGL(ph::k_fold_sums<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, d_p,
-                       d_keep, d_off, n_p, stride, (double*)dout);
+    {
+      ProfScope ps_(c, "k_fold_sums");
+      hipLaunchKernelGGL(ph::k_fold_sums<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, d_p,
+                         d_keep, d_off, n_p, stride, (double*)dout);
+    }
   }
   PH_TRY(launch_check("k_fold_sums"));
   return st.finish();
@@ -704,12 +809,18 @@ int ph_tile_sum(ph_ctx* c, const double* wts, int64_t W, int N, const int32_t* p
   const dim3 grid((unsigned)W);
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_tile_sum<double>, lds));
-    hipLaunchKernelGGL(ph::k_tile_sum<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dw, N, d_p,
-                       d_keep, d_off, n_p, stride, (double*)dout);
+    {
+      ProfScope ps_(c, "k_tile_sum");
+      hipLaunchKernelGGL(ph::k_tile_sum<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dw, N, d_p,
+                         d_keep, d_off, n_p, stride, (double*)dout);
+    }
   } else {
     PH_TRY(allow_lds(ph::k_tile_sum<float>, lds));
-    hipLaunchKernelGGL(ph::k_tile_sum<float>, grid, dim3(kBlock), lds, c->stream, (const double*)dw, N, d_p,
-                       d_keep, d_off, n_p, stride, (float*)dout);
+    {
+      ProfScope ps_(c, "k_tile_sum");
+      hipLaunchKernelGGL(ph::k_tile_sum<float>, grid, dim3(kBlock), lds, c->stream, (const double*)dw, N, d_p,
+                         d_keep, d_off, n_p, stride, (float*)dout);
+    }
   }
   PH_TRY(launch_check("k_tile_sum"));
   return st.finish();
@@ -730,11 +841,17 @@ int ph_periodic_norm(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int 
   PH_TRY(st.out(B_OUT0, out, (size_t)W * sizeof(double), &dout));
   const dim3 grid((unsigned)W);
   if (dtype == PH_F64)
-    hipLaunchKernelGGL(ph::k_periodic_norm<double>, grid, dim3(kBlock), 0, c->stream, (const double*)dx, N, p,
-                       (double*)dout);
+    {
+      ProfScope ps_(c, "k_periodic_norm");
+      hipLaunchKernelGGL(ph::k_periodic_norm<double>, grid, dim3(kBlock), 0, c->stream, (const double*)dx, N, p,
+                         (double*)dout);
+    }
   else
-    hipLaunchKernelGGL(ph::k_periodic_norm<float>, grid, dim3(kBlock), 0, c->stream, (const float*)dx, N, p,
-                       (double*)dout);
+    {
+      ProfScope ps_(c, "k_periodic_norm");
+      hipLaunchKernelGGL(ph::k_periodic_norm<float>, grid, dim3(kBlock), 0, c->stream, (const float*)dx, N, p,
+                         (double*)dout);
+    }
   PH_TRY(launch_check("k_periodic_norm"));
   return st.finish();
 }
@@ -758,7 +875,10 @@ int ph_dict_project(ph_ctx* c, const double* x, const double* basis, int rows, i
     db = (const double*)c->buf[B_WS1].p;
     dout = (float*)c->buf[B_OUT0].p;
   }
-  hipLaunchKernelGGL(ph::k_dict_project, dim3((unsigned)rows), dim3(kBlock), 0, c->stream, dx, db, N, dout);
+  {
+    ProfScope ps_(c, "k_dict_project");
+    hipLaunchKernelGGL(ph::k_dict_project, dim3((unsigned)rows), dim3(kBlock), 0, c->stream, dx, db, N, dout);
+  }
   PH_TRY(launch_check("k_dict_project"));
   if (!device) {
     PH_HIP(hipMemcpyAsync(out, dout, (size_t)rows * N * 4, hipMemcpyDeviceToHost, c->stream));

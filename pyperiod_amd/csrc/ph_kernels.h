@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, T* __restrict__ bases_out,
                                                         double* __restrict__ dnorm_out,
-                                                        int* __restrict__ status_out) {
+                                                        int* __restrict__ status_out,
+                                                        int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* work = cv.take<T>(N);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x,
   if (tid == 0) {
     dnorm_out[w] = data_norm;
     status_out[w] = status;
+    if (sweeps_out) sweeps_out[w] = status == 2 ? iters - 1 : iters;  // all-p sweeps performed
   }
 }
 

@@ -154,6 +154,17 @@ class PeriodEngine:
         _ffi.check(self._lib.ph_timer_end(self._ctx, C.byref(ms)))
         return float(ms.value)
 
+    def profile(self, on: bool = True):
+        """Start (or stop) bracketing every kernel launch with HIP events on the stream."""
+        _ffi.check(self._lib.ph_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self):
+        """-> [(kernel name, milliseconds)] for every launch since profile(True)."""
+        n = C.c_int(0)
+        buf = (C.c_float * 256)()
+        _ffi.check(self._lib.ph_profile_read(self._ctx, buf, 256, C.byref(n)))
+        return [(self._lib.ph_profile_name(self._ctx, i).decode(), float(buf[i])) for i in range(min(n.value, 256))]
+
     def max_window(self, dtype=np.float64, trunc=False, orth=False) -> int:
         n = C.c_int(0)
         code = _NP_DTYPES[np.dtype(dtype)]
@@ -194,8 +205,9 @@ class PeriodEngine:
             )
         return out
 
-    def m_best(self, x, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False):
-        """-> periods (W,num) uint32, powers (W,num) f64, bases (W,num,N), status (W) int32."""
+    def m_best(self, x, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False, want_sweeps=False):
+        """-> periods (W,num) uint32, powers (W,num) f64, bases (W,num,N), status (W) int32
+        [, n_sweeps (W) int32 when want_sweeps]."""
         x, code, W, N, fl, mk = self._prep(x)
         if max_length is None:
             max_length = N // 3
@@ -206,14 +218,18 @@ class PeriodEngine:
         powers = mk.empty((W, num), np.float64)
         bases = mk.empty((W, num, N), self._np_dtype(code))
         status = mk.empty((W,), np.int32)
+        sweeps = mk.empty((W,), np.int32) if want_sweeps else None
         with self._lock:
             _ffi.check(
                 self._lib.ph_m_best(
                     self._ctx, mk.addr(x), code, W, N, num, min_length, max_length, 1 if gamma else 0,
                     keep[2], keep[3], foff.ctypes.data, fq.ctypes.data, max(max_length, 1),
                     fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status),
+                    mk.addr(sweeps),
                 )
             )
+        if want_sweeps:
+            return periods, powers, bases, status, sweeps
         return periods, powers, bases, status
 
     def small_to_large(self, x, thresh=0.1, n_periods=None, trunc=False, orth=False, cap=16, want_bases=True):

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 20
     for name in names:
         assert hasattr(lib, name), f"{name} declared in periodhip.h but not exported"
-    assert sorted(list(_ffi.SIGNATURES) + ["ph_last_error"]) == names
+    assert sorted(list(_ffi.SIGNATURES) + ["ph_last_error", "ph_profile_name"]) == names
     assert lib.ph_version() == 100
 
 
