@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,10 @@ struct ph_ctx {
   int lds_limit = 0;
   DevBuf buf[B_COUNT];
   TableSlot tab[T_COUNT];
+  // per-period fold geometry for the tuned sweeps, cached for the last (N, max_p)
+  DevBuf geom;
+  int geom_n = -1, geom_max_p = -1;
+  int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
   int prof_n = 0;
@@ -114,6 +119,29 @@ int upload_table(ph_ctx* c, int slot, const int32_t* src, size_t n, const int** 
 }
 
 size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
+
+// Dense table geom[p], p in [0, max_p]: rows, nfull and the reciprocal counts of period p.
+int prepare_geom(ph_ctx* c, int N, int max_p, const ph::PGeom** out) {
+  if (c->geom.p && c->geom_n == N && c->geom_max_p >= max_p) {
+    *out = static_cast<const ph::PGeom*>(c->geom.p);
+    return PH_OK;
+  }
+  std::vector<ph::PGeom> host((size_t)max_p + 1);
+  host[0] = ph::PGeom{0, 0, 0.0, 0.0};
+  for (int p = 1; p <= max_p; ++p) {
+    const int rows = (N + p - 1) / p;
+    const int shortn = rows * p - N;
+    host[p] = ph::PGeom{rows, p - shortn, 1.0 / rows, rows > 1 ? 1.0 / (rows - 1) : 0.0};
+  }
+  PH_HIP(hipStreamSynchronize(c->stream));
+  PH_TRY(ensure(c, c->geom, host.size() * sizeof(ph::PGeom)));
+  PH_HIP(hipMemcpyAsync(c->geom.p, host.data(), host.size() * sizeof(ph::PGeom), hipMemcpyHostToDevice, c->stream));
+  PH_HIP(hipStreamSynchronize(c->stream));
+  c->geom_n = N;
+  c->geom_max_p = max_p;
+  *out = static_cast<const ph::PGeom*>(c->geom.p);
+  return PH_OK;
+}
 
 int check_common(ph_ctx* c, const void* x, int dtype, int64_t W, int N) {
   if (!c) return fail(PH_E_ARG, "ctx is NULL");
@@ -263,6 +291,8 @@ int pick_chunks(ph_ctx* c, int64_t W, int items, int min_items_per_chunk) {
 
 using ph::carve_bytes;
 using ph::kBlock;
+using ph::kBlockWide;
+using ph::kPad;
 using ph::kMaxWaves;
 using ph::kRedDoubles;
 
@@ -316,6 +346,10 @@ int ph_create(int device, ph_ctx** out) {
     return fail(PH_E_HIP, "stream/event creation: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("PH_SWEEP_BLOCK")) {
+    const int v = std::atoi(e);
+    if (v == 64 || v == 128 || v == 256 || v == 512) c->sweep_block = v;
+  }
   *out = c;
   return PH_OK;
 }
@@ -328,6 +362,7 @@ int ph_destroy(ph_ctx* c) {
     if (b.p) (void)hipFree(b.p);
   for (TableSlot& t : c->tab)
     if (t.dev.p) (void)hipFree(t.dev.p);
+  if (c->geom.p) (void)hipFree(c->geom.p);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -458,8 +493,10 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   const bool general = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) && mode != PH_SWEEP_MAXABS;
-  size_t lds = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8);
+  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8);
   PH_TRY(check_lds(c, lds, N, "ph_sweep"));
+  const ph::PGeom* geom;
+  PH_TRY(prepare_geom(c, N, p_hi, &geom));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, general ? flags : 0u, orth_off, orth_q, table_max_p, p_hi, &tb));
   const int P = p_hi - p_lo + 1;
@@ -468,22 +505,22 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   void* dout;
   PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
   PH_TRY(st.out(B_OUT0, out, (size_t)W * P * sizeof(double), &dout));
-  const int chunks = pick_chunks(c, W, P, 4 * (kBlock / 64));
+  const int chunks = pick_chunks(c, W, P, 8 * (c->sweep_block / 64));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)(W * chunks));
   if (dtype == PH_F64) {
     PH_TRY(allow_lds(ph::k_sweep<double>, lds));
     {
       ProfScope ps_(c, "k_sweep");
-      hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, p_lo,
-                         p_hi, mode, chunks, kflags, tb, (double*)dout);
+      hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, p_lo,
+                         p_hi, mode, chunks, kflags, tb, geom, (double*)dout);
     }
   } else {
     PH_TRY(allow_lds(ph::k_sweep<float>, lds));
     {
       ProfScope ps_(c, "k_sweep");
-      hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
-                         mode, chunks, kflags, tb, (double*)dout);
+      hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
+                         mode, chunks, kflags, tb, geom, (double*)dout);
     }
   }
   PH_TRY(launch_check("k_sweep"));
@@ -505,7 +542,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   const size_t sz = elem_size(dtype);
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const int P = max_length - min_length + 1;
-  size_t lds1 = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+  size_t lds1 = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
                 carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) + carve_bytes(num, 8) +
                 carve_bytes(num, 4) + carve_bytes((P + 31) / 32, 4);
   size_t lds2 = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(num, 8) + carve_bytes(num, 4);
@@ -513,6 +550,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, max_length, &tb));
   PH_TRY(prepare_fac(c, fac_off, fac_q, table_max_p, max_length, &tb));
+  const ph::PGeom* geom;
+  PH_TRY(prepare_geom(c, N, max_length, &geom));
   Stage st(c, flags);
   const void* dx;
   void *dper, *dpow, *dbases, *dstat;
@@ -533,8 +572,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     PH_TRY(allow_lds(ph::k_mbest_step2<double>, lds2));
     {
       ProfScope ps_(c, "k_mbest_step1");
-      hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(kBlock), lds1, c->stream, (const double*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
+      hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(c->sweep_block), lds1, c->stream, (const double*)dx, N, num,
+                         min_length, max_length, gamma, kflags, tb, geom, max_iters, (uint32_t*)dper, (double*)dpow,
                          (double*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     }
     PH_TRY(launch_check("k_mbest_step1"));
@@ -548,8 +587,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     PH_TRY(allow_lds(ph::k_mbest_step2<float>, lds2));
     {
       ProfScope ps_(c, "k_mbest_step1");
-      hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(kBlock), lds1, c->stream, (const float*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, max_iters, (uint32_t*)dper, (double*)dpow,
+      hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(c->sweep_block), lds1, c->stream, (const float*)dx, N, num,
+                         min_length, max_length, gamma, kflags, tb, geom, max_iters, (uint32_t*)dper, (double*)dpow,
                          (float*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     }
     PH_TRY(launch_check("k_mbest_step1"));
@@ -630,9 +669,11 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
-  size_t lds = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
                carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
   PH_TRY(check_lds(c, lds, N, "ph_best_correlation"));
+  const ph::PGeom* geom;
+  PH_TRY(prepare_geom(c, N, std::max(max_length, 2), &geom));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, std::max(max_length, 1), &tb));
   Stage st(c, flags);
@@ -649,16 +690,16 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
     PH_TRY(allow_lds(ph::k_best_correlation<double>, lds));
     {
       ProfScope ps_(c, "k_best_correlation");
-      hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                         num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
+      hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N,
+                         num, max_length, ratio, kflags, tb, geom, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
                          (int*)dstat);
     }
   } else {
     PH_TRY(allow_lds(ph::k_best_correlation<float>, lds));
     {
       ProfScope ps_(c, "k_best_correlation");
-      hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                         num, max_length, ratio, kflags, tb, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
+      hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N,
+                         num, max_length, ratio, kflags, tb, geom, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
                          (int*)dstat);
     }
   }

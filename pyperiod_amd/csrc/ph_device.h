@@ -18,7 +18,8 @@
 namespace ph {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;  // 4 wavefronts; 4 workgroups of 32 KiB windows fit one CU's 160 KiB LDS
+constexpr int kBlock = 256;      // 4 wavefronts: thread-per-residue / sequential kernels
+constexpr int kBlockWide = 512;  // 8 wavefronts: sweep kernels (4 workgroups x 32 KiB windows per CU -> 32 waves/CU)
 constexpr int kMaxWaves = 16;
 
 constexpr unsigned kTrunc = 1u;
@@ -196,6 +197,237 @@ __device__ __forceinline__ double wave_proj_sq(const T* __restrict__ xs, int N, 
   return v;
 }
 
+// ---------------------------------------------------------------- tuned wave-per-period fold
+// Per-period geometry, built once on the host for (N, p) and read with scalar loads: the hot
+// loop has no integer or floating-point division.
+struct PGeom {
+  int rows;        // R = ceil(N / p)
+  int nfull;       // residues j < nfull own R samples, the others R-1
+  double w_full;   // 1 / R
+  double w_short;  // 1 / (R-1)   (0 when R == 1)
+};
+
+constexpr int kPad = 64;  // LDS windows are followed by kPad zeroed elements (see fold_group)
+
+// One group of C consecutive 64-residue chunks of period p: lane owns residues
+// jbase + 64 c.  Rows 0..R-2 exist for every residue, so the row loop is wave-uniform and
+// branch-free: U rows x C chunks of independent ds_reads are in flight before the adds, the
+// chunks of one row share one address register (immediate offsets 512 c bytes).  Lanes whose
+// residue is >= p read at most 63 elements past the row -- inside the window or its zeroed
+// kPad tail -- and are discarded by a select.  Sums stay in row order per residue.
+// Accumulators of one period: squared sums of the residues that own R samples (`full`) and
+// R-1 samples (`shrt`), or the running max |S| in MAXABS mode (kept in `full`).
+struct FoldAcc {
+  double full = 0.0, shrt = 0.0;
+};
+
+template <typename T, int C, int U, bool MAXABS>
+__device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
+                                           FoldAcc& acc) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;  // 32-bit LDS address, ds_read
+  double s[C];
+  lds_ptr ptr[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    s[c] = 0.0;
+    ptr[c] = (lds_ptr)xs + lane + 64 * (c0 + c);
+    // one address register per chunk: with a shared base hipcc fuses chunk pairs into
+    // ds_read2st64_b64, which runs at half the LDS rate of ds_read_b64 (MI355X_MICROARCH.md LDS)
+    asm volatile("" : "+v"(ptr[c]));
+  }
+  const int full_rows = rows - 1;
+  int r = 0;
+  for (; r + U <= full_rows; r += U) {
+    T v[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[c][u * p];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) s[c] += (double)v[u][c];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ptr[c] += U * p;
+  }
+  for (; r < full_rows; ++r) {
+    T v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = ptr[c][0];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      s[c] += (double)v[c];
+      ptr[c] += p;
+    }
+  }
+  // ragged last row + squared accumulation; the class of a chunk (all residues own R samples /
+  // all own R-1 / mixed or partial) is wave-uniform, only one chunk per period is mixed
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j0 = 64 * (c0 + c);
+    if (j0 + 63 < nfull) {
+      const double t = s[c] + (double)ptr[c][0];
+      if (MAXABS)
+        acc.full = fmax(acc.full, fabs(t));
+      else
+        acc.full = fma(t, t, acc.full);
+    } else if (j0 >= nfull && j0 + 63 < p) {
+      if (MAXABS)
+        acc.full = fmax(acc.full, fabs(s[c]));
+      else
+        acc.shrt = fma(s[c], s[c], acc.shrt);
+    } else {
+      const int j = j0 + lane;
+      const bool has = j < nfull;
+      const T v = xs[has ? full_rows * p + j : 0];
+      const double t = (j < p) ? s[c] + (has ? (double)v : 0.0) : 0.0;
+      if (MAXABS) {
+        acc.full = fmax(acc.full, fabs(t));
+      } else {
+        const double tf = has ? t : 0.0, ts = has ? 0.0 : t;
+        acc.full = fma(tf, tf, acc.full);
+        acc.shrt = fma(ts, ts, acc.shrt);
+      }
+    }
+  }
+}
+
+// Per-lane partial of ||P_p x||^2 (or of max|S|) for p >= 64; the wavefront reduction of the
+// returned values is the result.
+template <typename T, bool MAXABS>
+__device__ __forceinline__ double wave_partial_large(const T* __restrict__ xs, int p, const PGeom& gref, int lane) {
+  // copy the geometry out of memory once (the caller's stores could alias it otherwise)
+  const int rows = gref.rows, nfull = gref.nfull;
+  const double w_full = gref.w_full, w_short = gref.w_short;
+  const int nchunks = (p + 63) >> 6;
+  FoldAcc acc;
+  int c0 = 0;
+  for (; c0 + 4 <= nchunks; c0 += 4) fold_group<T, 4, 2, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
+  switch (nchunks - c0) {
+    case 3: fold_group<T, 3, 2, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
+    case 2: fold_group<T, 2, 4, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
+    case 1: fold_group<T, 1, 8, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
+    default: break;
+  }
+  return MAXABS ? acc.full : acc.full * w_full + acc.shrt * w_short;
+}
+
+// p < 64, max|S| mode: one lane per residue, rows in order (bit-identical sums).
+template <typename T>
+__device__ __forceinline__ double wave_partial_small_maxabs(const T* __restrict__ xs, int p, const PGeom& g,
+                                                            int lane) {
+  if (lane >= p) return 0.0;
+  return fabs((double)column_sum(xs, lane, p, lane < g.nfull ? g.rows : g.rows - 1));
+}
+
+// p < 64: G = 64/p row groups fill the wavefront (lane = g p + j reads x[lane + r G p],
+// contiguous), partial sums of a residue are combined with G shuffles.  Summation order
+// differs from the reference's; only used where the reference's own order is undefined.
+template <typename T>
+__device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, int N, int p, const PGeom& g,
+                                                     int lane) {
+  const int G = 64 / p;
+  const int L = G * p;
+  const int full = N / L;  // rows of L elements that exist for every lane < L
+  const bool on = lane < L;
+  const T* ptr = xs + (on ? lane : 0);
+  double s0 = 0.0, s1 = 0.0;
+  int r = 0;
+  for (; r + 4 <= full; r += 4) {
+    const T a = ptr[0], b = ptr[L], c = ptr[2 * L], d = ptr[3 * L];
+    s0 += (double)a;
+    s1 += (double)b;
+    s0 += (double)c;
+    s1 += (double)d;
+    ptr += 4 * L;
+  }
+  for (; r < full; ++r) {
+    s0 += (double)ptr[0];
+    ptr += L;
+  }
+  const bool tail = on && (full * L + lane < N);
+  const T tv = xs[tail ? full * L + lane : 0];
+  double part = s0 + s1 + (tail ? (double)tv : 0.0);
+  part = on ? part : 0.0;
+  const int j = lane % p;
+  double tot = 0.0;
+  for (int gi = 0; gi < G; ++gi) tot += __shfl(part, j + gi * p, kWave);
+  const double w = (lane < g.nfull) ? g.w_full : g.w_short;
+  return (lane < p) ? tot * tot * w : 0.0;
+}
+
+template <typename T, bool MAXABS>
+__device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, int p, const PGeom& g, int lane) {
+  if (p >= 64) return wave_partial_large<T, MAXABS>(xs, p, g, lane);
+  return MAXABS ? wave_partial_small_maxabs(xs, p, g, lane) : wave_partial_small(xs, N, p, g, lane);
+}
+
+// Reduce 8 per-lane partials (8 periods) over the wavefront with 10 shuffles instead of 48:
+// after the call lane L holds the full sum of a[bit5(L)*4 + bit4(L)*2 + bit3(L)].
+template <bool MAXABS>
+__device__ __forceinline__ double butterfly8(const double (&a)[8], int lane) {
+  auto op = [](double x, double y) { return MAXABS ? fmax(x, y) : x + y; };
+  double b[4], c[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double keep = h5 ? a[i + 4] : a[i];
+    const double send = h5 ? a[i] : a[i + 4];
+    b[i] = op(keep, __shfl_xor(send, 32, kWave));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double keep = h4 ? b[i + 2] : b[i];
+    const double send = h4 ? b[i] : b[i + 2];
+    c[i] = op(keep, __shfl_xor(send, 16, kWave));
+  }
+  const double keep = h3 ? c[1] : c[0];
+  const double send = h3 ? c[0] : c[1];
+  double d = op(keep, __shfl_xor(send, 8, kWave));
+  d = op(d, __shfl_xor(d, 4, kWave));
+  d = op(d, __shfl_xor(d, 2, kWave));
+  d = op(d, __shfl_xor(d, 1, kWave));
+  return d;
+}
+
+__device__ __forceinline__ int butterfly8_slot(int lane) {
+  return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+}
+
+// Visit ||P_p x||^2 (or max_s |S_p[s]| when MAXABS) for p = p_first, p_first + stride, ...
+// <= p_hi, eight periods per cross-lane reduction.  consume(value, p) runs in the 8 lanes
+// that own period p.  p_first and stride must be wave-uniform.
+template <typename T, bool MAXABS, typename F>
+__device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
+                                           int p_first, int p_hi, int stride, int lane, F&& consume) {
+  for (int pb = p_first; pb <= p_hi; pb += 8 * stride) {
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int p = pb + k * stride;
+      a[k] = 0.0;
+      if (p <= p_hi) a[k] = wave_partial<T, MAXABS>(xs, N, p, geom[p], lane);
+    }
+    const double tot = butterfly8<MAXABS>(a, lane);
+    const int p = pb + butterfly8_slot(lane) * stride;
+    if (p <= p_hi) consume(tot, p);
+  }
+}
+
+// Wavefront argmax of (value, period): largest value, lowest period among equals
+// (the reference scans p upward with a strict '>', Periods.py:512).  period 0 = none.
+__device__ __forceinline__ void wave_argmax(double& v, int& p) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(v, o, kWave);
+    const int op = __shfl_xor(p, o, kWave);
+    if (op != 0 && (p == 0 || ov > v || (ov == v && op < p))) {
+      v = ov;
+      p = op;
+    }
+  }
+}
+
 // max_s |S_p[s]| with row-order sums (Periods.py:327-331), in every lane.
 template <typename T>
 __device__ __forceinline__ double wave_fold_maxabs(const T* __restrict__ xs, int N, int p, int lane) {
@@ -220,6 +452,11 @@ __device__ __forceinline__ double block_sweep_value(const T* __restrict__ xs, T*
 }
 
 // Copy one window HBM -> LDS (coalesced, 16-byte vectors when the row is 16-byte aligned).
+template <typename T>
+__device__ __forceinline__ void zero_pad(T* __restrict__ xs, int N) {
+  for (int i = threadIdx.x; i < kPad; i += blockDim.x) xs[N + i] = T(0);
+}
+
 template <typename T>
 __device__ __forceinline__ void load_window(const T* __restrict__ g, T* __restrict__ xs, int N) {
   constexpr int V = 16 / sizeof(T);

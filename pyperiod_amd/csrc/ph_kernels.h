@@ -76,12 +76,12 @@ __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ 
 //   the window load.  Flagged path: workgroup-cooperative full projection per period.
 // ======================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
-                                                  int chunks, unsigned flags, Tables tb,
-                                                  double* __restrict__ out) {
+__global__ __launch_bounds__(kBlockWide) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
+                                                      int chunks, unsigned flags, Tables tb,
+                                                      const PGeom* __restrict__ geom, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = cv.take<T>(N);
+  T* xs = cv.take<T>(N + kPad);
   const bool general = (flags & (kTrunc | kOrth)) && mode != 2;
   T* buf = general ? cv.take<T>(N) : nullptr;
   double* red = cv.take<double>(kRedDoubles);
@@ -93,21 +93,22 @@ __global__ __launch_bounds__(kBlock) void k_sweep(const T* __restrict__ x, int N
   const int pa = p_lo + c * per;
   const int pb = min(p_hi, pa + per - 1);
   load_window(x + w * (int64_t)N, xs, N);
+  zero_pad(xs, N);
   __syncthreads();
   double* orow = out + w * (int64_t)P;
 
   if (!general) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
-    for (int p = pa + wv; p <= pb; p += nw) {
-      double v;
-      if (mode == 2) {
-        v = wave_fold_maxabs(xs, N, p, lane);
-      } else {
-        v = periodic_norm_from_sq(wave_proj_sq(xs, N, p, lane), N, mode == 1 ? p : 0);
-      }
-      if (lane == 0) orow[p - p_lo] = v;
+    if (mode == 2) {
+      wave_sweep<T, true>(xs, N, geom, pa + wv, pb, nw, lane, [&](double v, int p) {
+        if ((lane & 7) == 0) orow[p - p_lo] = v;
+      });
+    } else {
+      wave_sweep<T, false>(xs, N, geom, pa + wv, pb, nw, lane, [&](double v, int p) {
+        if ((lane & 7) == 0) orow[p - p_lo] = periodic_norm_from_sq(v, N, mode == 1 ? p : 0);
+      });
     }
   } else {
     for (int p = pa; p <= pb; ++p) {
@@ -122,8 +123,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep(const T* __restrict__ x, int N
 // distinct periods are found.  One workgroup per window, one launch per window batch.
 // ======================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
+__global__ __launch_bounds__(kBlockWide) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
+                                                        const PGeom* __restrict__ geom,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, T* __restrict__ bases_out,
                                                         double* __restrict__ dnorm_out,
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x,
                                                         int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N);
+  T* work = cv.take<T>(N + kPad);
   const bool general = flags & (kTrunc | kOrth);
   T* buf = general ? cv.take<T>(N) : nullptr;
   double* red = cv.take<double>(kRedDoubles);
@@ -145,19 +147,18 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x,
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wv = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   T* bases = bases_out + w * (int64_t)num * N;
 
   load_window(x + w * (int64_t)N, work, N);
+  zero_pad(work, N);
   for (int k = tid; k < num; k += blockDim.x) {
     norms[k] = 0.0;
     periods[k] = 0u;
   }
   for (int k = tid; k < (P + 31) / 32; k += blockDim.x) skip[k] = 0u;
   __syncthreads();
-  // rows the algorithm never fills stay zero, like np.zeros((num, N)) at Periods.py:490
-  for (int64_t n = tid; n < (int64_t)num * N; n += blockDim.x) bases[n] = T(0);
   const double data_norm = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
 
   int filled = 0;   // `i` of Periods.py:494
@@ -173,14 +174,15 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x,
     double best = 0.0;
     int bestp = 0;
     if (!general) {
-      for (int p = p_lo + wv; p <= p_hi; p += nw) {
-        const double v = periodic_norm_from_sq(wave_proj_sq(work, N, p, lane), N, gamma ? p : 0);
+      wave_sweep<T, false>(work, N, geom, p_lo + wv, p_hi, nw, lane, [&](double ss, int p) {
+        const double v = periodic_norm_from_sq(ss, N, gamma ? p : 0);
         const bool skipped = (skip[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u;
         if (v > best && !skipped) {
           best = v;
           bestp = p;
         }
-      }
+      });
+      wave_argmax(best, bestp);
       if (lane == 0) {
         wbest[wv] = best;
         wbestp[wv] = bestp;
@@ -265,6 +267,8 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step1(const T* __restrict__ x,
     __syncthreads();
   }
   __syncthreads();
+  // rows the algorithm never filled stay zero, like np.zeros((num, N)) at Periods.py:490
+  for (int64_t n = (int64_t)filled * N + tid; n < (int64_t)num * N; n += blockDim.x) bases[n] = T(0);
   for (int k = tid; k < num; k += blockDim.x) {
     periods_out[w * num + k] = periods[k];
     norms_out[w * num + k] = norms[k];
@@ -521,15 +525,16 @@ __global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__
 // Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.
 // ======================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_best_correlation(const T* __restrict__ x, int N, int num,
+__global__ __launch_bounds__(kBlockWide) void k_best_correlation(const T* __restrict__ x, int N, int num,
                                                              int max_length, double ratio, unsigned flags,
-                                                             Tables tb, uint32_t* __restrict__ periods_out,
+                                                             Tables tb, const PGeom* __restrict__ geom,
+                                                             uint32_t* __restrict__ periods_out,
                                                              double* __restrict__ norms_out,
                                                              T* __restrict__ bases_out,
                                                              int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N);
+  T* work = cv.take<T>(N + kPad);
   const bool general = flags & (kTrunc | kOrth);
   T* buf = general ? cv.take<T>(N) : nullptr;
   double* red = cv.take<double>(kRedDoubles);
@@ -539,10 +544,11 @@ __global__ __launch_bounds__(kBlock) void k_best_correlation(const T* __restrict
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wv = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   T* bases = bases_out + w * (int64_t)num * N;
   load_window(x + w * (int64_t)N, work, N);
+  zero_pad(work, N);
   __syncthreads();
   const double sqrtN = sqrt((double)N);
   const double og = sqrt(block_sumsq(work, N, red)) / sqrtN;  // :316
@@ -558,13 +564,13 @@ __global__ __launch_bounds__(kBlock) void k_best_correlation(const T* __restrict
       // argmax over (p, s) of |sum(x[s::p])|, strict '>' in p-major order (:324-331)
       double best = 0.0;
       int bestp = 0;
-      for (int p = 2 + wv; p < max_length; p += nw) {
-        const double v = wave_fold_maxabs(work, N, p, lane);
+      wave_sweep<T, true>(work, N, geom, 2 + wv, max_length - 1, nw, lane, [&](double v, int p) {
         if (v > best) {
           best = v;
           bestp = p;
         }
-      }
+      });
+      wave_argmax(best, bestp);
       if (lane == 0) {
         wbest[wv] = best;
         wbestp[wv] = bestp;
