@@ -545,7 +545,10 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   size_t lds1 = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
                 carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) + carve_bytes(num, 8) +
                 carve_bytes(num, 4) + carve_bytes((P + 31) / 32, 4);
-  size_t lds2 = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(num, 8) + carve_bytes(num, 4);
+  int max_fac = 1;  // most proper divisors any candidate period has
+  for (int q = 0; q <= max_length; ++q) max_fac = std::max(max_fac, fac_off ? fac_off[q + 1] - fac_off[q] : 0);
+  size_t lds2 = carve_bytes(N + kPad, sz) + carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) +
+                carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8);
   PH_TRY(check_lds(c, std::max(lds1, lds2), N, "ph_m_best"));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, max_length, &tb));
@@ -580,7 +583,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     {
       ProfScope ps_(c, "k_mbest_step2");
       hipLaunchKernelGGL(ph::k_mbest_step2<double>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                         kflags, tb, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
+                         kflags, tb, geom, max_fac, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
     }
   } else {
     PH_TRY(allow_lds(ph::k_mbest_step1<float>, lds1));
@@ -595,7 +598,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     {
       ProfScope ps_(c, "k_mbest_step2");
       hipLaunchKernelGGL(ph::k_mbest_step2<float>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                         kflags, tb, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
+                         kflags, tb, geom, max_fac, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
     }
   }
   PH_TRY(launch_check("k_mbest_step2"));

@@ -96,11 +96,27 @@ struct Fold {
 };
 
 // Row-order column sum of residue j over `n` rows: ((x[j] + x[p+j]) + x[2p+j]) + ...
+// Eight independent loads are issued ahead of their eight dependent adds, so the chain costs
+// an add latency per row instead of an LDS round trip; the order of the adds is unchanged.
 template <typename T>
 __device__ __forceinline__ T column_sum(const T* __restrict__ xs, int j, int p, int n) {
   if (n <= 0) return T(0);
-  T s = xs[j];
-  for (int r = 1; r < n; ++r) s += xs[r * p + j];
+  const T* ptr = xs + j;
+  T s = ptr[0];
+  ptr += p;
+  int r = 1;
+  for (; r + 8 <= n; r += 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ptr[u * p];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+    ptr += 8 * p;
+  }
+  for (; r < n; ++r) {
+    s += ptr[0];
+    ptr += p;
+  }
   return s;
 }
 
@@ -224,17 +240,14 @@ struct FoldAcc {
 template <typename T, int C, int U, bool MAXABS>
 __device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
                                            FoldAcc& acc) {
-  typedef const __attribute__((address_space(3))) T* lds_ptr;  // 32-bit LDS address, ds_read
+  // LDS reads go through a volatile LDS-address-space pointer: the chunks of one row then share
+  // one address register (immediate offsets 512 c), and hipcc cannot fuse chunk pairs into
+  // ds_read2st64_b64, which runs at half the LDS rate of ds_read_b64 (MI355X_MICROARCH.md LDS)
+  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
   double s[C];
-  lds_ptr ptr[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    s[c] = 0.0;
-    ptr[c] = (lds_ptr)xs + lane + 64 * (c0 + c);
-    // one address register per chunk: with a shared base hipcc fuses chunk pairs into
-    // ds_read2st64_b64, which runs at half the LDS rate of ds_read_b64 (MI355X_MICROARCH.md LDS)
-    asm volatile("" : "+v"(ptr[c]));
-  }
+  for (int c = 0; c < C; ++c) s[c] = 0.0;
+  lds_ptr ptr = (lds_ptr)xs + lane + 64 * c0;
   const int full_rows = rows - 1;
   int r = 0;
   for (; r + U <= full_rows; r += U) {
@@ -242,23 +255,20 @@ __device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int 
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int c = 0; c < C; ++c) v[u][c] = ptr[c][u * p];
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < C; ++c) s[c] += (double)v[u][c];
-#pragma unroll
-    for (int c = 0; c < C; ++c) ptr[c] += U * p;
+    ptr += U * p;
   }
   for (; r < full_rows; ++r) {
     T v[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = ptr[c][0];
+    for (int c = 0; c < C; ++c) v[c] = ptr[64 * c];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      s[c] += (double)v[c];
-      ptr[c] += p;
-    }
+    for (int c = 0; c < C; ++c) s[c] += (double)v[c];
+    ptr += p;
   }
   // ragged last row + squared accumulation; the class of a chunk (all residues own R samples /
   // all own R-1 / mixed or partial) is wave-uniform, only one chunk per period is mixed
@@ -266,7 +276,7 @@ __device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int 
   for (int c = 0; c < C; ++c) {
     const int j0 = 64 * (c0 + c);
     if (j0 + 63 < nfull) {
-      const double t = s[c] + (double)ptr[c][0];
+      const double t = s[c] + (double)ptr[64 * c];
       if (MAXABS)
         acc.full = fmax(acc.full, fabs(t));
       else

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlockWide) void k_sweep(const T* __restrict__ x, i
 // distinct periods are found.  One workgroup per window, one launch per window batch.
 // ======================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlockWide) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
                                                         const PGeom* __restrict__ geom,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
@@ -288,25 +288,32 @@ __global__ __launch_bounds__(kBlockWide) void k_mbest_step1(const T* __restrict_
 // ======================================================================================
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
-                                                        Tables tb, uint32_t* __restrict__ periods_io,
+                                                        Tables tb, const PGeom* __restrict__ geom, int max_fac,
+                                                        uint32_t* __restrict__ periods_io,
                                                         double* __restrict__ norms_io, T* __restrict__ bases_io,
                                                         const double* __restrict__ dnorm,
                                                         const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* rowbuf = cv.take<T>(N);
+  T* rowbuf = cv.take<T>(N + kPad);
   T* buf = cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
   double* norms = cv.take<double>(num);
   uint32_t* periods = cv.take<uint32_t>(num);
+  double* fvals = cv.take<double>(max_fac > 0 ? max_fac : 1);
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const bool general = flags & (kTrunc | kOrth);
   T* bases = bases_io + w * (int64_t)num * N;
   for (int k = tid; k < num; k += blockDim.x) {
     norms[k] = norms_io[w * num + k];
     periods[k] = periods_io[w * num + k];
   }
+  zero_pad(rowbuf, N);
   __syncthreads();
 
   const int gdiv = gamma ? stale_p : 0;
@@ -318,14 +325,32 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamm
     double top = 0.0, last = 0.0;
     int topf = -1;
     const int a = tb.fac_off[per], b = tb.fac_off[per + 1];
-    for (int k = a; k < b; ++k) {
-      const int f = tb.fac_q[k];
-      const double v = block_sweep_value(rowbuf, buf, N, f, gdiv, flags, tb, red);
-      if (v > top) {
-        top = v;
-        topf = f;
+    if (!general) {
+      // one wavefront per factor: ||P_f row||^2 = sum_j S_f[j]^2 / cnt_f[j]
+      for (int k = a + wv; k < b; k += nw) {
+        const int f = tb.fac_q[k];
+        const double ss = wave_sum(wave_partial<T, false>(rowbuf, N, f, geom[f], lane));
+        if (lane == 0) fvals[k - a] = periodic_norm_from_sq(ss, N, gdiv);
       }
-      last = v;
+      __syncthreads();
+      for (int k = a; k < b; ++k) {  // the reference's scan order (Periods.py:549-563)
+        const double v = fvals[k - a];
+        if (v > top) {
+          top = v;
+          topf = tb.fac_q[k];
+        }
+        last = v;
+      }
+    } else {
+      for (int k = a; k < b; ++k) {
+        const int f = tb.fac_q[k];
+        const double v = block_sweep_value(rowbuf, buf, N, f, gdiv, flags, tb, red);
+        if (v > top) {
+          top = v;
+          topf = f;
+        }
+        last = v;
+      }
     }
     bool split = false;
     if (topf >= 0) {
@@ -342,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamm
       i += 1;
       continue;
     }
-    // recompute the winning factor's projection (bit-identical), then
+    // materialise the winning factor's projection exactly, then
     //   rows i+2.. <- rows i+1.. ; row i+1 <- row i - proj ; row i <- proj   (:581-594)
     project_lds(rowbuf, buf, N, topf, flags, tb);
     for (int r = num - 1; r >= i + 2; --r) {
