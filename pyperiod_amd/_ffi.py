@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libperiod_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("PYPERIOD_AMD_LIB") or os.path.join(_HERE, LIB_NAME)  # override = tuning builds
 
 PH_OK, PH_E_ARG, PH_E_HIP, PH_E_NOMEM, PH_E_CAP, PH_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 PH_F64, PH_F32 = 0, 1

@@ -348,7 +348,7 @@ int ph_create(int device, ph_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = std::getenv("PH_SWEEP_BLOCK")) {
     const int v = std::atoi(e);
-    if (v == 64 || v == 128 || v == 256 || v == 512) c->sweep_block = v;
+    if (v >= 64 && v <= 512 && v % 64 == 0) c->sweep_block = v;
   }
   *out = c;
   return PH_OK;

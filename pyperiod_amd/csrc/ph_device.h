@@ -223,80 +223,104 @@ struct PGeom {
   double w_short;  // 1 / (R-1)   (0 when R == 1)
 };
 
-constexpr int kPad = 64;  // LDS windows are followed by kPad zeroed elements (see fold_group)
+constexpr int kPad = 512;  // LDS windows are followed by kPad zeroed elements (see fold_group)
 
-// One group of C consecutive 64-residue chunks of period p: lane owns residues
-// jbase + 64 c.  Rows 0..R-2 exist for every residue, so the row loop is wave-uniform and
-// branch-free: U rows x C chunks of independent ds_reads are in flight before the adds, the
-// chunks of one row share one address register (immediate offsets 512 c bytes).  Lanes whose
-// residue is >= p read at most 63 elements past the row -- inside the window or its zeroed
-// kPad tail -- and are discarded by a select.  Sums stay in row order per residue.
 // Accumulators of one period: squared sums of the residues that own R samples (`full`) and
 // R-1 samples (`shrt`), or the running max |S| in MAXABS mode (kept in `full`).
 struct FoldAcc {
   double full = 0.0, shrt = 0.0;
 };
 
-template <typename T, int C, int U, bool MAXABS>
-__device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
-                                           FoldAcc& acc) {
-  // LDS reads go through a volatile LDS-address-space pointer: the chunks of one row then share
-  // one address register (immediate offsets 512 c), and hipcc cannot fuse chunk pairs into
-  // ds_read2st64_b64, which runs at half the LDS rate of ds_read_b64 (MI355X_MICROARCH.md LDS)
-  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
-  double s[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) s[c] = 0.0;
-  lds_ptr ptr = (lds_ptr)xs + lane + 64 * c0;
-  const int full_rows = rows - 1;
+// s[c] += sum over `nrows` rows of the C chunks starting at `ptr` (row stride p).  U rows x C
+// chunks of independent ds_read_b64 are issued back to back, then ONE lgkmcnt(0) (the scalar
+// issue slot is as busy as the vector one here; the other waves of the CU cover the latency),
+// then the adds.  The reads go through a volatile LDS-address-space pointer: the chunks of a
+// row share one address register (immediate offsets 512 c) and hipcc cannot fuse chunk pairs
+// into ds_read2st64_b64, which runs at half the LDS rate of ds_read_b64.  Row order per
+// residue is preserved (bit-identical column sums).
+template <typename T, int C, int U>
+__device__ __forceinline__ void fold_rows(const volatile __attribute__((address_space(3))) T* ptr, int p,
+                                          int nrows, double (&s)[C]) {
   int r = 0;
-  for (; r + U <= full_rows; r += U) {
+  for (; r + U <= nrows; r += U) {
     T v[U][C];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < C; ++c) s[c] += (double)v[u][c];
     ptr += U * p;
   }
-  for (; r < full_rows; ++r) {
-    T v[C];
+  if (U > 1) {
+    for (; r < nrows; ++r) {
+      T v[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = ptr[64 * c];
+      for (int c = 0; c < C; ++c) v[c] = ptr[64 * c];
 #pragma unroll
-    for (int c = 0; c < C; ++c) s[c] += (double)v[c];
-    ptr += p;
+      for (int c = 0; c < C; ++c) s[c] += (double)v[c];
+      ptr += p;
+    }
   }
-  // ragged last row + squared accumulation; the class of a chunk (all residues own R samples /
-  // all own R-1 / mixed or partial) is wave-uniform, only one chunk per period is mixed
+}
+
+// One group of C consecutive 64-residue chunks of period p; lane owns residues
+// 64 (c0 + c) + lane.  Whether all residues of the group own R samples, all own R-1, or the
+// group straddles nfull / p is wave-uniform; only one or two groups per period take the
+// general path.  Lanes whose residue is >= p read at most 64 C - 1 elements past a row --
+// inside the window or its zeroed kPad tail -- and are discarded by a select.
+template <typename T, int C, int U, bool MAXABS>
+__device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
+                                           FoldAcc& acc) {
+  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
+  double s[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const int j0 = 64 * (c0 + c);
-    if (j0 + 63 < nfull) {
-      const double t = s[c] + (double)ptr[64 * c];
-      if (MAXABS)
-        acc.full = fmax(acc.full, fabs(t));
-      else
-        acc.full = fma(t, t, acc.full);
-    } else if (j0 >= nfull && j0 + 63 < p) {
+  for (int c = 0; c < C; ++c) s[c] = 0.0;
+  const lds_ptr base = (lds_ptr)xs + lane + 64 * c0;
+  const int jlo = 64 * c0, jhi = jlo + 64 * C;
+  const bool all_full = jhi <= nfull;                 // every residue of the group owns R samples
+  const bool all_short = jlo >= nfull && jhi <= p;    // every residue owns R-1 samples
+  fold_rows<T, C, U>(base, p, all_full ? rows : rows - 1, s);
+  if (all_full || all_short) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
       if (MAXABS)
         acc.full = fmax(acc.full, fabs(s[c]));
+      else if (all_full)
+        acc.full = fma(s[c], s[c], acc.full);
       else
         acc.shrt = fma(s[c], s[c], acc.shrt);
-    } else {
-      const int j = j0 + lane;
-      const bool has = j < nfull;
-      const T v = xs[has ? full_rows * p + j : 0];
-      const double t = (j < p) ? s[c] + (has ? (double)v : 0.0) : 0.0;
-      if (MAXABS) {
-        acc.full = fmax(acc.full, fabs(t));
-      } else {
-        const double tf = has ? t : 0.0, ts = has ? 0.0 : t;
-        acc.full = fma(tf, tf, acc.full);
-        acc.shrt = fma(ts, ts, acc.shrt);
+    }
+  } else {
+    // the group straddles nfull and/or p: classify chunk by chunk (still wave-uniform); at most
+    // two chunks of a period need the per-lane selects
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j0 = jlo + 64 * c;
+      if (j0 + 64 <= nfull) {
+        const double t = s[c] + (double)base[(rows - 1) * p + 64 * c];
+        acc.full = MAXABS ? fmax(acc.full, fabs(t)) : fma(t, t, acc.full);
+      } else if (j0 >= nfull && j0 + 64 <= p) {
+        if (MAXABS)
+          acc.full = fmax(acc.full, fabs(s[c]));
+        else
+          acc.shrt = fma(s[c], s[c], acc.shrt);
+      } else if (j0 < p) {
+        const int j = j0 + lane;
+        const bool has = j < nfull;
+        const T v = xs[has ? (rows - 1) * p + j : 0];
+        const double t = (j < p) ? s[c] + (has ? (double)v : 0.0) : 0.0;
+        if (MAXABS) {
+          acc.full = fmax(acc.full, fabs(t));
+        } else {
+          const double tf = has ? t : 0.0, ts = has ? 0.0 : t;
+          acc.full = fma(tf, tf, acc.full);
+          acc.shrt = fma(ts, ts, acc.shrt);
+        }
       }
     }
   }
@@ -312,7 +336,21 @@ __device__ __forceinline__ double wave_partial_large(const T* __restrict__ xs, i
   const int nchunks = (p + 63) >> 6;
   FoldAcc acc;
   int c0 = 0;
-  for (; c0 + 4 <= nchunks; c0 += 4) fold_group<T, 4, 2, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
+#ifndef PH_MAIN_C8
+#define PH_MAIN_C8 0
+#endif
+#ifndef PH_C4_U
+#define PH_C4_U 2
+#endif
+#if PH_MAIN_C8
+  for (; c0 + 8 <= nchunks; c0 += 8) fold_group<T, 8, 1, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
+  if (c0 + 4 <= nchunks) {
+    fold_group<T, 4, PH_C4_U, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
+    c0 += 4;
+  }
+#else
+  for (; c0 + 4 <= nchunks; c0 += 4) fold_group<T, 4, PH_C4_U, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
+#endif
   switch (nchunks - c0) {
     case 3: fold_group<T, 3, 2, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
     case 2: fold_group<T, 2, 4, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
@@ -372,53 +410,58 @@ __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, 
   return MAXABS ? wave_partial_small_maxabs(xs, p, g, lane) : wave_partial_small(xs, N, p, g, lane);
 }
 
-// Reduce 8 per-lane partials (8 periods) over the wavefront with 10 shuffles instead of 48:
-// after the call lane L holds the full sum of a[bit5(L)*4 + bit4(L)*2 + bit3(L)].
+// Cross-lane reduction of 8 consecutive periods with 10 shuffles instead of 48, "online":
+// period k's per-lane partial is merged as soon as it is complete (level 1 pairs periods over
+// lane bit 5, level 2 pairs of pairs over bit 4, level 3 over bit 3), so the period loop stays
+// rolled -- one copy of the fold code in the instruction cache -- and at most three partials
+// are pending.  Afterwards lane L holds the full value of period slot
+// bit5(L) + 2 bit4(L) + 4 bit3(L) of the block.
 template <bool MAXABS>
-__device__ __forceinline__ double butterfly8(const double (&a)[8], int lane) {
-  auto op = [](double x, double y) { return MAXABS ? fmax(x, y) : x + y; };
-  double b[4], c[2];
-  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const double keep = h5 ? a[i + 4] : a[i];
-    const double send = h5 ? a[i] : a[i + 4];
-    b[i] = op(keep, __shfl_xor(send, 32, kWave));
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const double keep = h4 ? b[i + 2] : b[i];
-    const double send = h4 ? b[i] : b[i + 2];
-    c[i] = op(keep, __shfl_xor(send, 16, kWave));
-  }
-  const double keep = h3 ? c[1] : c[0];
-  const double send = h3 ? c[0] : c[1];
-  double d = op(keep, __shfl_xor(send, 8, kWave));
-  d = op(d, __shfl_xor(d, 4, kWave));
-  d = op(d, __shfl_xor(d, 2, kWave));
-  d = op(d, __shfl_xor(d, 1, kWave));
-  return d;
+__device__ __forceinline__ double butterfly_merge(double lo, double hi, int mask, int lane) {
+  const bool up = lane & mask;
+  const double keep = up ? hi : lo;
+  const double send = up ? lo : hi;
+  const double got = __shfl_xor(send, mask, kWave);
+  return MAXABS ? fmax(keep, got) : keep + got;
 }
 
 __device__ __forceinline__ int butterfly8_slot(int lane) {
-  return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+  return ((lane >> 5) & 1) + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1) * 4;
 }
 
 // Visit ||P_p x||^2 (or max_s |S_p[s]| when MAXABS) for p = p_first, p_first + stride, ...
-// <= p_hi, eight periods per cross-lane reduction.  consume(value, p) runs in the 8 lanes
-// that own period p.  p_first and stride must be wave-uniform.
+// <= p_hi.  consume(value, p) runs in the 8 lanes that own period p.  p_first and stride
+// must be wave-uniform.
 template <typename T, bool MAXABS, typename F>
 __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
                                            int p_first, int p_hi, int stride, int lane, F&& consume) {
   for (int pb = p_first; pb <= p_hi; pb += 8 * stride) {
-    double a[8];
-#pragma unroll
+    double l1 = 0.0, l2 = 0.0, l3 = 0.0, tot = 0.0;
     for (int k = 0; k < 8; ++k) {
       const int p = pb + k * stride;
-      a[k] = 0.0;
-      if (p <= p_hi) a[k] = wave_partial<T, MAXABS>(xs, N, p, geom[p], lane);
+      double a = 0.0;
+      if (p <= p_hi) a = wave_partial<T, MAXABS>(xs, N, p, geom[p], lane);
+      if ((k & 1) == 0) {
+        l1 = a;
+        continue;
+      }
+      a = butterfly_merge<MAXABS>(l1, a, 32, lane);
+      if ((k & 2) == 0) {
+        l2 = a;
+        continue;
+      }
+      a = butterfly_merge<MAXABS>(l2, a, 16, lane);
+      if ((k & 4) == 0) {
+        l3 = a;
+        continue;
+      }
+      tot = butterfly_merge<MAXABS>(l3, a, 8, lane);
     }
-    const double tot = butterfly8<MAXABS>(a, lane);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      const double got = __shfl_xor(tot, o, kWave);
+      tot = MAXABS ? fmax(tot, got) : tot + got;
+    }
     const int p = pb + butterfly8_slot(lane) * stride;
     if (p <= p_hi) consume(tot, p);
   }

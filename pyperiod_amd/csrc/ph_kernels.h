@@ -122,8 +122,11 @@ __global__ __launch_bounds__(kBlockWide) void k_sweep(const T* __restrict__ x, i
 // m_best step 1  (Periods.py:494-537): repeat { all-p sweep, argmax, subtract } until `num`
 // distinct periods are found.  One workgroup per window, one launch per window batch.
 // ======================================================================================
+#ifndef PH_STEP1_WAVES
+#define PH_STEP1_WAVES 8
+#endif
 template <typename T>
-__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
                                                         const PGeom* __restrict__ geom,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
