@@ -448,8 +448,8 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
   }
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  size_t lds = carve_bytes(N, sz);
-  if (flags & PH_FLAG_ORTH) lds += carve_bytes(N, sz);
+  const int scratch_len = (flags & PH_FLAG_ORTH) ? N : std::min(pmax, N);
+  size_t lds = carve_bytes(N, sz) + carve_bytes(scratch_len, sz);
   PH_TRY(check_lds(c, lds, N, "ph_project_batch"));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, pmax, &tb));
@@ -469,14 +469,14 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
     {
       ProfScope ps_(c, "k_project_batch");
       hipLaunchKernelGGL(ph::k_project_batch<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                         d_plist, n_p, chunks, kflags, tb, (double*)dout);
+                         d_plist, n_p, chunks, kflags, tb, scratch_len, (double*)dout);
     }
   } else {
     PH_TRY(allow_lds(ph::k_project_batch<float>, lds));
     {
       ProfScope ps_(c, "k_project_batch");
       hipLaunchKernelGGL(ph::k_project_batch<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                         d_plist, n_p, chunks, kflags, tb, (float*)dout);
+                         d_plist, n_p, chunks, kflags, tb, scratch_len, (float*)dout);
     }
   }
   PH_TRY(launch_check("k_project_batch"));
@@ -616,9 +616,11 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
-  size_t lds = carve_bytes(N, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
-               carve_bytes(kBlock, 8);
+  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+               carve_bytes(ph::kS2LBatch, 8) + carve_bytes(4, 4);
   PH_TRY(check_lds(c, lds, N, "ph_small_to_large"));
+  const ph::PGeom* geom;
+  PH_TRY(prepare_geom(c, N, std::max(n_periods, 2), &geom));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, std::max(n_periods, 1), &tb));
   Stage st(c, flags);
@@ -638,16 +640,16 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
     PH_TRY(allow_lds(ph::k_small_to_large<double>, lds));
     {
       ProfScope ps_(c, "k_small_to_large");
-      hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                         thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow,
+      hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N,
+                         thresh, n_periods, kflags, tb, geom, cap, (int*)dcnt, (int*)dper, (double*)dpow,
                          (double*)dbases, (int*)dstat);
     }
   } else {
     PH_TRY(allow_lds(ph::k_small_to_large<float>, lds));
     {
       ProfScope ps_(c, "k_small_to_large");
-      hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                         thresh, n_periods, kflags, tb, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
+      hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N,
+                         thresh, n_periods, kflags, tb, geom, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
                          (int*)dstat);
     }
   }

@@ -26,6 +26,12 @@ __host__ __device__ inline size_t carve_bytes(size_t n, size_t elem) { return (n
 
 constexpr int kRedDoubles = 2 * kMaxWaves;
 
+// The sweep kernels run 4 workgroups x 8 wavefronts per CU (LDS holds four 32 KiB windows), which
+// needs <= 64 VGPRs; measured +15 % over the 5 waves/SIMD the unconstrained allocation gives.
+#ifndef PH_STEP1_WAVES
+#define PH_STEP1_WAVES 8
+#endif
+
 // ======================================================================================
 // K1  Periods.project over a batch  (Periods.py:142-219)
 //   grid.x = W * chunks; each workgroup projects its window onto p_list[k0 .. k1).
@@ -35,11 +41,13 @@ constexpr int kRedDoubles = 2 * kMaxWaves;
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ x, int N,
                                                           const int* __restrict__ p_list, int n_p, int chunks,
-                                                          unsigned flags, Tables tb, T* __restrict__ out) {
+                                                          unsigned flags, Tables tb, int scratch_len,
+                                                          T* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* xs = cv.take<T>(N);
-  T* buf = (flags & kOrth) ? cv.take<T>(N) : nullptr;
+  // orth: the whole projection is materialised here; otherwise only one period of means
+  T* buf = cv.take<T>(scratch_len);
 
   const int64_t w = blockIdx.x / chunks;
   const int c = blockIdx.x % chunks;
@@ -51,21 +59,49 @@ __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ 
 
   const bool trunc = flags & kTrunc;
   const bool single = flags & kSingle;
+  constexpr int V = 16 / sizeof(T);
   for (int k = k0; k < k1; ++k) {
     const int p = p_list[k];
     T* orow = out + (w * n_p + k) * (int64_t)N;
+    const int lim = single ? min(p, N) : N;
     if (!(flags & kOrth)) {
+      // means in row order (bit-identical to the reference), one per residue that exists
       const Fold f(N, p);
-      for (int j = threadIdx.x; j < p; j += blockDim.x) {
-        const T m = residue_mean(xs, f, j, trunc);
-        const int cnt = single ? (j < N ? 1 : 0) : f.count(j);
-        for (int r = 0; r < cnt; ++r) orow[r * p + j] = m;
+      const int np = min(p, N);
+      for (int j = threadIdx.x; j < np; j += blockDim.x) buf[j] = residue_mean(xs, f, j, trunc);
+      __syncthreads();
+      // tile (Periods.py:196-198): coalesced 16-byte stores, n mod p kept incrementally
+      if ((N % V) == 0 && (lim % V) == 0) {
+        using vec_t = typename std::conditional<sizeof(T) == 8, double2, float4>::type;
+        const int stride = blockDim.x * V;
+        int j = (threadIdx.x * V) % p;
+        const int step = stride % p;
+        for (int n = threadIdx.x * V; n < lim; n += stride) {
+          T v[V];
+          int jj = j;
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            v[e] = buf[jj];
+            jj = (jj + 1 == p) ? 0 : jj + 1;
+          }
+          *reinterpret_cast<vec_t*>(orow + n) = *reinterpret_cast<const vec_t*>(v);
+          j += step;
+          if (j >= p) j -= p;
+        }
+      } else {
+        int j = threadIdx.x % p;
+        const int step = blockDim.x % p;
+        for (int n = threadIdx.x; n < lim; n += blockDim.x) {
+          orow[n] = buf[j];
+          j += step;
+          if (j >= p) j -= p;
+        }
       }
+      __syncthreads();  // buf is rewritten by the next period
     } else {
       project_lds(xs, buf, N, p, flags, tb);
-      const int lim = single ? min(p, N) : N;
       for (int n = threadIdx.x; n < lim; n += blockDim.x) orow[n] = buf[n];
-      __syncthreads();  // buf is rewritten by the next period
+      __syncthreads();
     }
   }
 }
@@ -76,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ 
 //   the window load.  Flagged path: workgroup-cooperative full projection per period.
 // ======================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlockWide) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
                                                       int chunks, unsigned flags, Tables tb,
                                                       const PGeom* __restrict__ geom, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -122,9 +158,6 @@ __global__ __launch_bounds__(kBlockWide) void k_sweep(const T* __restrict__ x, i
 // m_best step 1  (Periods.py:494-537): repeat { all-p sweep, argmax, subtract } until `num`
 // distinct periods are found.  One workgroup per window, one launch per window batch.
 // ======================================================================================
-#ifndef PH_STEP1_WAVES
-#define PH_STEP1_WAVES 8
-#endif
 template <typename T>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
@@ -415,63 +448,31 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamm
 //   and evaluate the reference's expression exactly (second pass) whenever the screen is
 //   within its own error bound of the threshold, so the accept decision is the exact one.
 // ======================================================================================
-template <typename T>
-__device__ __forceinline__ double block_proj_sq(const T* __restrict__ xs, int N, int p, double* scratch,
-                                                double* red) {
-  const Fold f(N, p);
-  const int tid = threadIdx.x;
-  const int nthr = blockDim.x;
-  double a = 0.0, b = 0.0;
-  if (p >= nthr) {
-    for (int j = tid; j < p; j += nthr) {
-      const bool full = j < f.nfull;
-      const double s = (double)column_sum(xs, j, p, full ? f.rows : f.rows - 1);
-      if (full)
-        a += s * s;
-      else
-        b += s * s;
-    }
-  } else {
-    // G row groups of p lanes: thread t sums x[t], x[t+L], ... with L = G*p (contiguous reads)
-    const int G = nthr / p;
-    const int L = G * p;
-    double part = 0.0;
-    if (tid < L)
-      for (int n = tid; n < N; n += L) part += (double)xs[n];
-    scratch[tid] = part;
-    __syncthreads();
-    if (tid < p) {
-      double s = 0.0;
-      for (int g = 0; g < G; ++g) s += scratch[tid + g * p];
-      if (tid < f.nfull)
-        a = s * s;
-      else
-        b = s * s;
-    }
-  }
-  block_sum2(a, b, red);
-  double v = a / (double)f.rows;
-  if (f.rows > 1) v += b / (double)(f.rows - 1);
-  return v;
-}
+constexpr int kS2LBatch = 64;  // periods screened speculatively per round (8 waves x 8 periods)
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
-                                                           int n_periods, unsigned flags, Tables tb, int cap,
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
+                                                           int n_periods, unsigned flags, Tables tb,
+                                                           const PGeom* __restrict__ geom, int cap,
                                                            int* __restrict__ counts, int* __restrict__ periods_out,
                                                            double* __restrict__ powers_out,
                                                            T* __restrict__ bases_out, int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N);
+  T* work = cv.take<T>(N + kPad);
   const bool general = flags & (kTrunc | kOrth);
   T* buf = general ? cv.take<T>(N) : nullptr;
   double* red = cv.take<double>(kRedDoubles);
-  double* scratch = cv.take<double>(kBlock);
+  double* psq = cv.take<double>(kS2LBatch);
+  int* cand_slot = cv.take<int>(4);
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
   load_window(x + w * (int64_t)N, work, N);
+  zero_pad(work, N);
   __syncthreads();
   double rsq = block_sumsq(work, N, red);
   const double sqrtN = sqrt((double)N);
@@ -479,32 +480,54 @@ __global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__
   double rn = dn;                       // periodic_norm(residual)
   int count = 0;
 
-  for (int p = 2; p <= n_periods; ++p) {
-    bool evaluate = true;
+  int p = 2;
+  while (p <= n_periods) {
+    int cand = p;  // the period that gets the exact evaluation of Periods.py:274-281
     if (!general) {
-      const double psq = block_proj_sq(work, N, p, scratch, red);
-      const double tsq = fmax(rsq - psq, 0.0);
-      const double tn_est = sqrt(tsq) / sqrtN;
-      const double est = (rn - tn_est) / dn;
-      // error of tn_est from the cancellation in rsq - psq, relative to data_norm
-      const double err = (16.0 * 2.220446049250313e-16 * rsq / fmax(sqrt(tsq), 1e-300)) / sqrtN / dn + 1e-13;
-      evaluate = !(est + err <= thresh);  // NaN -> evaluate
+      // The residual only changes when a period is accepted, so a run of periods can be
+      // screened in parallel (wave-per-period): ||r - P r||^2 = ||r||^2 - ||P r||^2 gives an
+      // estimate of the reference's norm drop.  The first period whose estimate, plus a bound
+      // on its cancellation error, reaches the threshold is evaluated exactly below; results
+      // screened beyond an accepted period are discarded and recomputed.
+      const int hi = min(n_periods, p + kS2LBatch - 1);
+      wave_sweep<T, false>(work, N, geom, p + wv, hi, nw, lane, [&](double ss, int q) {
+        if ((lane & 7) == 0) psq[q - p] = ss;
+      });
+      __syncthreads();
+      if (wv == 0) {  // one lane per screened period; the first flagged one is the candidate
+        const int q = p + lane;
+        bool flag = false;
+        if (q <= hi) {
+          const double tsq = fmax(rsq - psq[lane], 0.0);
+          const double est = (rn - sqrt(tsq) / sqrtN) / dn;
+          const double err =
+              (4096.0 * 2.220446049250313e-16 * rsq / fmax(sqrt(tsq), 1e-300)) / sqrtN / dn + 1e-13;
+          flag = !(est + err <= thresh);  // NaN -> evaluate
+        }
+        const unsigned long long mask = __ballot(flag);
+        if (lane == 0) *cand_slot = mask ? p + __ffsll((long long)mask) - 1 : -1;
+      }
+      __syncthreads();  // also: psq is rewritten by the next round
+      cand = *cand_slot;
+      if (cand < 0) {
+        p = hi + 1;
+        continue;
+      }
     }
-    if (!evaluate) continue;
-    // exact evaluation of Periods.py:274-281
+    // exact evaluation (row-order means, direct sum of squares of the trial residual)
     double tsq = 0.0;
     if (!general) {
-      const Fold f(N, p);
-      for (int j = tid; j < p; j += blockDim.x) {
+      const Fold f(N, cand);
+      for (int j = tid; j < cand; j += blockDim.x) {
         const T m = residue_mean(work, f, j, false);
         const int cnt = f.count(j);
         for (int r = 0; r < cnt; ++r) {
-          const double t = (double)(work[r * p + j] - m);
+          const double t = (double)(work[r * cand + j] - m);
           tsq += t * t;
         }
       }
     } else {
-      project_lds(work, buf, N, p, flags, tb);
+      project_lds(work, buf, N, cand, flags, tb);
       for (int n = tid; n < N; n += blockDim.x) {
         const double t = (double)(work[n] - buf[n]);
         tsq += t * t;
@@ -516,12 +539,12 @@ __global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__
     if (imposed > thresh) {  // strict, Periods.py:281
       T* brow = (bases_out && count < cap) ? bases_out + (w * cap + count) * (int64_t)N : nullptr;
       if (!general) {
-        const Fold f(N, p);
-        for (int j = tid; j < p; j += blockDim.x) {
+        const Fold f(N, cand);
+        for (int j = tid; j < cand; j += blockDim.x) {
           const T m = residue_mean(work, f, j, false);
           const int cnt = f.count(j);
           for (int r = 0; r < cnt; ++r) {
-            const int n = r * p + j;
+            const int n = r * cand + j;
             if (brow) brow[n] = m;
             work[n] -= m;
           }
@@ -534,14 +557,15 @@ __global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__
         }
       }
       if (tid == 0 && count < cap) {
-        periods_out[w * cap + count] = p;
+        periods_out[w * cap + count] = cand;
         powers_out[w * cap + count] = imposed;
       }
       count += 1;
       rsq = tsq;
       rn = tn;
-      __syncthreads();
     }
+    __syncthreads();
+    p = cand + 1;
   }
   if (tid == 0) {
     counts[w] = count;
@@ -553,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_small_to_large(const T* __restrict__
 // Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.
 // ======================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlockWide) void k_best_correlation(const T* __restrict__ x, int N, int num,
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_best_correlation(const T* __restrict__ x, int N, int num,
                                                              int max_length, double ratio, unsigned flags,
                                                              Tables tb, const PGeom* __restrict__ geom,
                                                              uint32_t* __restrict__ periods_out,
