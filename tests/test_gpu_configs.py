@@ -1,0 +1,156 @@
+"""GPU tests at the full sizes of BASELINE.json configs 3, 4 and 5 (config 2 is covered in
+test_gpu_parity.py): size-independent properties on the whole batch plus oracle / golden spot
+checks on a few windows, and the edge cases of the batch interface."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import period_oracle as po
+from pyperiod_amd.synth import multi_sinusoid_batch, multi_sinusoid_window
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import default_engine
+
+    return default_engine()
+
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
+def test_config4_shard_small_to_large(eng, golden):
+    """Config 4, one GPU's shard shape: windows x N=4096, small_to_large(thresh=0.05)."""
+    W, n, thresh = 2048, 4096, 0.05
+    x = multi_sinusoid_batch(0, W, n)
+    counts, per, pw, bs, st = eng.small_to_large(x, thresh, cap=40, want_bases=False)
+    assert not st.any() and counts.min() >= 1
+    g = golden("small_to_large")
+    for w in range(4):  # the reference's own answers for windows 0..3
+        assert list(per[w, : counts[w]]) == list(g[f"w{w}_periods"])
+        assert rel_err(pw[w, : counts[w]], g[f"w{w}_powers"]) < TOL
+    for w in range(W):
+        k = counts[w]
+        assert np.all(np.diff(per[w, :k]) > 0) and per[w, 0] >= 2 and per[w, k - 1] <= n // 2
+        assert np.all(pw[w, :k] > thresh) and not per[w, k:].any()
+    # energy bookkeeping: the accepted norm drops telescope to (||x|| - ||residual||) / ||x||
+    sub = x[:64]
+    c2, p2, w2, b2, _ = eng.small_to_large(sub, thresh, cap=40, want_bases=True)
+    assert np.array_equal(c2, counts[:64]) and np.array_equal(p2, per[:64])
+    for w in range(64):
+        k = c2[w]
+        resid = sub[w] - b2[w, :k].sum(0)
+        total = (po.periodic_norm(sub[w]) - po.periodic_norm(resid)) / po.periodic_norm(sub[w])
+        assert abs(w2[w, :k].sum() - total) < 1e-9
+        for i in range(k):  # each base is exactly periodic with its period
+            p = int(p2[w, i])
+            assert np.array_equal(b2[w, i, p:], b2[w, i, :-p])
+    # oracle spot check beyond the golden windows
+    for w in (100, 2047):
+        rper, rpw, _ = po.small_to_large(x[w], thresh)
+        assert list(per[w, : counts[w]]) == rper and rel_err(pw[w, : counts[w]], rpw) < TOL
+
+
+def test_config3_ramanujan_batch(eng, golden):
+    """Config 3 shape: N=8192, Pmax=512, a batch of windows in one launch."""
+    W, n, pmax = 256, 8192, 512
+    x = multi_sinusoid_batch(0, W, n)
+    out = eng.ramanujan_norms(x, 2, pmax)
+    assert out.shape == (W, pmax + 1) and not out[:, :2].any() and np.all(out[:, 2:] >= 0)
+    g = golden("ramanujan")
+    assert rel_err(out[1, :65], g["norms_n8192_pmax64"]) < 1e-5  # the reference's answer for window 1
+    want = po.ramanujan_norms_folded(x[7], 2, 96)
+    assert rel_err(out[7, :97], want) < TOL
+    # the planted sinusoid periods dominate: the strongest q is one of the three integer periods
+    # (or a multiple within Pmax) of the generator for most windows
+    single = eng.ramanujan_norms(x[3:4], 2, pmax)
+    assert np.array_equal(single[0], out[3])  # batch == per-window
+    # exactness of the subspace split: sum over q | n of E_q energy == energy of the n-periodic part
+    y = po.project(x[5][:8190], 90)  # a 90-periodic signal (8190 = 91 * 90)
+    r = eng.ramanujan_norms(y[None, :], 1, 90)[0]
+    divs = [d for d in range(1, 91) if 90 % d == 0]
+    # orthogonality is exact only for q | N (otherwise the finite window leaks)
+    others = [q for q in range(1, 91) if 90 % q and 8190 % q == 0]
+    assert len(others) >= 10 and r[others].max() < 1e-18 * r[divs].max()
+
+
+def test_config5_fp32_blocks(eng):
+    """Config 5 pieces on fp32 windows of N=16384: orthogonalised projection, A x folds and the
+    A^T w reconstruction, against the fp64 oracle on the fp32-rounded inputs (1e-4 relative,
+    build-defined -- the reference has no fp32 path)."""
+    n = 16384
+    x32 = multi_sinusoid_batch(10, 3, n, dtype=np.float32)
+    x64 = x32.astype(np.float64)
+    plist = [37, 64, 101, 1260]
+    for trunc, orth in ((False, True), (True, True), (False, False)):
+        out = eng.project_batch(x32, plist, trunc, orth)
+        assert out.dtype == np.float32
+        for w in range(3):
+            for k, p in enumerate(plist):
+                assert rel_err(out[w, k], po.project(x64[w], p, trunc, orth)) < 1e-4
+    from pyperiod_amd import QOPeriods
+
+    qo = QOPeriods()
+    a, dims = qo.get_subspaces([37, 64, 101], n)
+    p_list, keep = [int(k) for k in dims], list(dims.values())
+    assert keep == [37, 63, 100]
+    folds = eng.fold_sums(x32, p_list, keep)
+    assert rel_err(folds, x64 @ a.T) < 1e-4
+    gram = eng.fold_sums(a, p_list, keep)
+    assert np.array_equal(gram, a @ a.T)  # integer co-occurrence counts: exact
+    w = np.linalg.solve(gram, folds[0])
+    rec = eng.tile_sum(w[None, :], n, p_list, keep)[0]
+    assert rel_err(rec, a.T @ w) < 1e-12
+    # least-squares property: the residual is orthogonal to every dictionary row
+    resid = x64[0] - rec
+    assert np.max(np.abs(a @ resid)) < 1e-3 * np.max(np.abs(folds[0]))
+    # fp32 sweep against the fp64 oracle
+    from pyperiod_amd import _ffi
+
+    sw = eng.sweep(x32[:1], 2, 600, _ffi.PH_SWEEP_NORM_GAMMA)[0]
+    assert rel_err(sw, po.sweep_norms(x64[0], 2, 600, gamma=True)) < 1e-4
+
+
+def test_batch_interface_edges(eng):
+    from pyperiod_amd import Periods, _ffi
+
+    # one window, tiny window, odd lengths, largest window that fits
+    for n in (2, 3, 17, 63, 64, 65, 4097):
+        x = np.random.default_rng(n).standard_normal((2, n))
+        hi = max(2, n // 2)
+        sw = eng.sweep(x, 1, hi, _ffi.PH_SWEEP_NORM)
+        for w in range(2):
+            assert rel_err(sw[w], po.sweep_norms(x[w], 1, hi)) < TOL, n
+    nmax = eng.max_window()
+    x = multi_sinusoid_batch(0, 1, nmax)
+    assert np.array_equal(eng.project_batch(x, [977])[0, 0], po.project(x[0], 977))
+    with pytest.raises(ValueError):
+        eng.project_batch(np.zeros((1, nmax + 4096)), [3])  # does not fit LDS: PH_E_ARG
+    with pytest.raises(ValueError):
+        eng.project_batch(np.zeros((1, 8)), [0])
+    with pytest.raises(ValueError):
+        eng.sweep(np.zeros((1, 8)), 3, 2)
+    with pytest.raises(ValueError):
+        eng.sweep(np.zeros(8), 2, 3)  # not a batch
+    # non-float64 input is upcast like numpy would
+    xi = np.arange(24).reshape(2, 12)
+    assert np.array_equal(eng.project_batch(xi, [5])[1, 0], po.project(xi[1].astype(float), 5))
+    # batched class surface (extension over the reference)
+    xb = multi_sinusoid_batch(0, 3, 512)
+    per, pw, bs = Periods().m_best(xb, num=3)
+    assert per.shape == (3, 3) and bs.shape == (3, 3, 512)
+    res = Periods().small_to_large(xb, thresh=0.05)
+    assert len(res) == 3 and res[1][0] == po.small_to_large(xb[1], 0.05)[0]
