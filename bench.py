@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-root-leg", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +174,36 @@ def main():
 
     periods, powers, bases, status, sweeps = out
     assert int(status.abs().sum().item()) == 0, "a window failed in m_best"
+
+    # Optional second leg (N > 1 only, outside the timed region): the batch starts on rank 0,
+    # is scattered with RCCL, processed, and the fixed-shape results are gathered back --
+    # the "RCCL scatter/gather over xGMI" deployment shape.  Never part of `value`.
+    root_leg = None
+    if world > 1 and not args.no_root_leg:
+        try:
+            from pyperiod_amd.dist import gather_rows, scatter_windows
+
+            total = world * WINDOWS_PER_GPU
+            x_root = torch.cat([x] * world, 0) if rank == 0 else None  # synthetic: rank 0's windows repeated
+            barrier()
+            t1 = time.perf_counter()
+            xl = scatter_windows(x_root, total, N_SAMPLES, torch.float64, dev)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            o = eng.m_best(xl, NUM_PERIODS, None, 2, False)
+            torch.cuda.synchronize(dev)
+            t3 = time.perf_counter()
+            g_per = gather_rows(o[0], total)
+            g_pow = gather_rows(o[1], total)
+            barrier()
+            t4 = time.perf_counter()
+            root_leg = {"scatter_ms": 1e3 * (t2 - t1), "compute_ms": 1e3 * (t3 - t2), "gather_ms": 1e3 * (t4 - t3),
+                        "total_ms": 1e3 * (t4 - t1), "windows": total,
+                        "note": "input on rank 0 -> RCCL scatter -> m_best -> RCCL gather of periods/powers"}
+            if rank == 0:
+                assert g_per.shape == (total, NUM_PERIODS) and g_pow.shape == (total, NUM_PERIODS)
+        except Exception as exc:  # the headline number must survive a failure of this leg
+            root_leg = {"error": repr(exc)}
     proj_local = int(sweeps.sum().item()) * P  # per step on this rank
     tproj = torch.tensor([float(proj_local)], device=dev, dtype=torch.float64)
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -227,6 +258,8 @@ def main():
             },
             "cpu_baseline": cpu,
         }
+        if root_leg is not None:
+            line["rccl_root_leg"] = root_leg
         if cpu:
             line["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(line), flush=True)
