@@ -70,6 +70,8 @@ struct ph_ctx {
   // per-period fold geometry for the tuned sweeps, cached for the last (N, max_p)
   DevBuf geom;
   int geom_n = -1, geom_max_p = -1;
+  DevBuf plan;  // pass plan of the norm sweeps, cached for the last (p_lo, p_hi)
+  int plan_lo = -1, plan_hi = -1, plan_n = 0;
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
@@ -119,6 +121,41 @@ int upload_table(ph_ctx* c, int slot, const int32_t* src, size_t n, const int** 
 }
 
 size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
+
+// Pass plan of a norm sweep over [p_lo, p_hi]: every period is produced exactly once, either
+// by its own pass or as 2p / 4p of a smaller base period (see PassPlan in ph_device.h).
+// Periods below 64 use the row-split path one at a time (m = 0).
+int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass) {
+  if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi) {
+    *out = static_cast<const ph::PassPlan*>(c->plan.p);
+    *n_pass = c->plan_n;
+    return PH_OK;
+  }
+  std::vector<ph::PassPlan> host;
+  std::vector<char> covered((size_t)p_hi + 1, 0);
+  for (int p = p_lo; p <= p_hi; ++p) {
+    if (p < 64) {
+      host.push_back(ph::PassPlan{p, 0});
+      continue;
+    }
+    if (covered[p]) continue;
+    const int m = (4LL * p <= p_hi) ? 4 : (2LL * p <= p_hi) ? 2 : 1;
+    for (int d = 1; d <= m; d *= 2) covered[(size_t)d * p] = 1;
+    host.push_back(ph::PassPlan{p, m});
+  }
+  PH_HIP(hipStreamSynchronize(c->stream));
+  PH_TRY(ensure(c, c->plan, std::max<size_t>(1, host.size()) * sizeof(ph::PassPlan)));
+  if (!host.empty())
+    PH_HIP(hipMemcpyAsync(c->plan.p, host.data(), host.size() * sizeof(ph::PassPlan), hipMemcpyHostToDevice,
+                          c->stream));
+  PH_HIP(hipStreamSynchronize(c->stream));
+  c->plan_lo = p_lo;
+  c->plan_hi = p_hi;
+  c->plan_n = (int)host.size();
+  *out = static_cast<const ph::PassPlan*>(c->plan.p);
+  *n_pass = c->plan_n;
+  return PH_OK;
+}
 
 // Dense table geom[p], p in [0, max_p]: rows, nfull and the reciprocal counts of period p.
 int prepare_geom(ph_ctx* c, int N, int max_p, const ph::PGeom** out) {
@@ -363,6 +400,7 @@ int ph_destroy(ph_ctx* c) {
   for (TableSlot& t : c->tab)
     if (t.dev.p) (void)hipFree(t.dev.p);
   if (c->geom.p) (void)hipFree(c->geom.p);
+  if (c->plan.p) (void)hipFree(c->plan.p);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -497,6 +535,9 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   PH_TRY(check_lds(c, lds, N, "ph_sweep"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, p_hi, &geom));
+  const ph::PassPlan* plan;
+  int n_pass;
+  PH_TRY(prepare_plan(c, p_lo, p_hi, &plan, &n_pass));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, general ? flags : 0u, orth_off, orth_q, table_max_p, p_hi, &tb));
   const int P = p_hi - p_lo + 1;
@@ -513,14 +554,14 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
     {
       ProfScope ps_(c, "k_sweep");
       hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, p_lo,
-                         p_hi, mode, chunks, kflags, tb, geom, (double*)dout);
+                         p_hi, mode, chunks, kflags, tb, geom, plan, n_pass, (double*)dout);
     }
   } else {
     PH_TRY(allow_lds(ph::k_sweep<float>, lds));
     {
       ProfScope ps_(c, "k_sweep");
       hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
-                         mode, chunks, kflags, tb, geom, (double*)dout);
+                         mode, chunks, kflags, tb, geom, plan, n_pass, (double*)dout);
     }
   }
   PH_TRY(launch_check("k_sweep"));
@@ -555,6 +596,9 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   PH_TRY(prepare_fac(c, fac_off, fac_q, table_max_p, max_length, &tb));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, max_length, &geom));
+  const ph::PassPlan* plan;
+  int n_pass;
+  PH_TRY(prepare_plan(c, min_length, max_length, &plan, &n_pass));
   Stage st(c, flags);
   const void* dx;
   void *dper, *dpow, *dbases, *dstat;
@@ -576,7 +620,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     {
       ProfScope ps_(c, "k_mbest_step1");
       hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(c->sweep_block), lds1, c->stream, (const double*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, geom, max_iters, (uint32_t*)dper, (double*)dpow,
+                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, max_iters, (uint32_t*)dper, (double*)dpow,
                          (double*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     }
     PH_TRY(launch_check("k_mbest_step1"));
@@ -591,7 +635,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     {
       ProfScope ps_(c, "k_mbest_step1");
       hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(c->sweep_block), lds1, c->stream, (const float*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, geom, max_iters, (uint32_t*)dper, (double*)dpow,
+                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, max_iters, (uint32_t*)dper, (double*)dpow,
                          (float*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     }
     PH_TRY(launch_check("k_mbest_step1"));

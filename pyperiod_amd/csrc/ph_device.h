@@ -467,6 +467,185 @@ __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, cons
   }
 }
 
+// ---------------------------------------------------------------- multi-period passes
+// One pass over the window at base period p also yields the folds of 2p and 4p: row r of the
+// p-fold belongs to residue j + (r mod m) p of the (m p)-fold, so keeping one accumulator per
+// row parity class (m = 2) or per r mod 4 (m = 4) gives S_2p / S_4p exactly, and S_p as their
+// sums, for the LDS traffic and the adds of a single period.  The host plans the passes so that
+// every candidate period is produced exactly once (plan_passes in period_hip.hip).
+struct PassPlan {
+  int p;  // base period
+  int m;  // 1, 2 or 4: the pass yields p, 2p (m >= 2) and 4p (m == 4); 0: p < 64, row-split path
+};
+
+struct DerivedGeom {  // count classes of a produced period q
+  int nfull;
+  double w_full, w_short;
+};
+
+template <typename T, int M, int C>
+__device__ __forceinline__ void pass_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
+                                           const DerivedGeom (&dg)[3], double (&part)[3]) {
+  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
+  double a[M][C];  // a[u][c]: rows r = u (mod M) of residue 64 (c0 + c) + lane
+#pragma unroll
+  for (int u = 0; u < M; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) a[u][c] = 0.0;
+  lds_ptr ptr = (lds_ptr)xs + lane + 64 * c0;
+  const int full_rows = rows - 1;  // rows every residue owns
+  const int nblk = full_rows / M;
+  for (int b = 0; b < nblk; ++b) {
+    T v[M][C];
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see fold_rows
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u][c] += (double)v[u][c];
+    ptr += M * p;
+  }
+  // tail block: rows nblk M + u exist in full for u < rem; row u == rem is the ragged last row
+  const int rem = full_rows - nblk * M;
+#pragma unroll
+  for (int u = 0; u < M; ++u) {
+    if (u < rem) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u][c] += (double)ptr[u * p + 64 * c];
+    } else if (u == rem) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int j = 64 * (c0 + c) + lane;
+        const bool has = j < nfull;
+        const T t = xs[has ? full_rows * p + j : 0];
+        a[u][c] += has ? (double)t : 0.0;
+      }
+    }
+  }
+  auto emit = [&](int t, int i, double val) {
+    const double w = (i < dg[t].nfull) ? dg[t].w_full : dg[t].w_short;
+    part[t] = fma(val, val * w, part[t]);
+  };
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = 64 * (c0 + c) + lane;
+    if (64 * (c0 + c) + 64 > p) {  // the chunk that contains p: lanes past the period hold garbage
+#pragma unroll
+      for (int u = 0; u < M; ++u) a[u][c] = (j < p) ? a[u][c] : 0.0;
+    }
+    if (M == 2) {
+      emit(0, j, a[0][c] + a[1][c]);
+      emit(1, j, a[0][c]);
+      emit(1, j + p, a[1][c]);
+    } else {
+      const double e = a[0][c] + a[2 % M][c], o = a[1][c] + a[3 % M][c];
+      emit(0, j, e + o);
+      emit(1, j, e);
+      emit(1, j + p, o);
+#pragma unroll
+      for (int u = 0; u < M; ++u) emit(2, j + u * p, a[u][c]);
+    }
+  }
+}
+
+// Per-lane partials of ||P_q x||^2 for q = p, 2p (and 4p when M == 4); p >= 64.
+template <typename T, int M>
+__device__ __forceinline__ void wave_pass(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom, int lane,
+                                          double (&part)[3]) {
+  const int rows = geom[p].rows, nfull = geom[p].nfull;
+  DerivedGeom dg[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int q = (t == 0 || (t == 1) || M == 4) ? (p << t) : p;
+    dg[t].nfull = geom[q].nfull;
+    dg[t].w_full = geom[q].w_full;
+    dg[t].w_short = geom[q].w_short;
+    part[t] = 0.0;
+  }
+  const int nchunks = (p + 63) >> 6;
+  constexpr int CM = (M == 4) ? 2 : 4;
+  int c0 = 0;
+  for (; c0 + CM <= nchunks; c0 += CM) pass_group<T, M, CM>(xs, p, rows, nfull, c0, lane, dg, part);
+  if (CM == 4 && c0 + 2 <= nchunks) {
+    pass_group<T, M, 2>(xs, p, rows, nfull, c0, lane, dg, part);
+    c0 += 2;
+  }
+  if (c0 < nchunks) pass_group<T, M, 1>(xs, p, rows, nfull, c0, lane, dg, part);
+}
+
+// The online 8-period butterfly of wave_sweep as a state machine, for producers that deliver
+// one to three periods at a time.  `k` is wave-uniform.
+struct Butterfly8 {
+  double l1, l2, l3;
+  int k, myp;
+  __device__ __forceinline__ void reset() {
+    k = 0;
+    myp = 0;
+    l1 = l2 = l3 = 0.0;
+  }
+  template <typename F>
+  __device__ __forceinline__ void push(double a, int p, int lane, F&& consume) {
+    if (butterfly8_slot(lane) == k) myp = p;
+    if ((k & 1) == 0) {
+      l1 = a;
+    } else {
+      a = butterfly_merge<false>(l1, a, 32, lane);
+      if ((k & 2) == 0) {
+        l2 = a;
+      } else {
+        a = butterfly_merge<false>(l2, a, 16, lane);
+        if ((k & 4) == 0) {
+          l3 = a;
+        } else {
+          double tot = butterfly_merge<false>(l3, a, 8, lane);
+#pragma unroll
+          for (int o = 4; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+          if (myp != 0) consume(tot, myp);
+          myp = 0;
+        }
+      }
+    }
+    k = (k + 1) & 7;
+  }
+  template <typename F>
+  __device__ __forceinline__ void flush(int lane, F&& consume) {
+    while (k != 0) push(0.0, 0, lane, consume);
+  }
+};
+
+// Norm sweep driven by a pass plan: visits ||P_q x||^2 of every period the passes
+// plan[i_first], plan[i_first + stride], ... (< i_end) produce.  Periods arrive out of order;
+// consume(value, q) runs in the 8 lanes that own q.
+template <typename T, typename F>
+__device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
+                                                const PassPlan* __restrict__ plan, int i_first, int i_end,
+                                                int stride, int lane, F&& consume) {
+  Butterfly8 bf;
+  bf.reset();
+  for (int i = i_first; i < i_end; i += stride) {
+    const int p = plan[i].p, m = plan[i].m;
+    if (m <= 1) {
+      bf.push(wave_partial<T, false>(xs, N, p, geom[p], lane), p, lane, consume);
+    } else if (m == 2) {
+      double part[3];
+      wave_pass<T, 2>(xs, p, geom, lane, part);
+      bf.push(part[0], p, lane, consume);
+      bf.push(part[1], 2 * p, lane, consume);
+    } else {
+      double part[3];
+      wave_pass<T, 4>(xs, p, geom, lane, part);
+      bf.push(part[0], p, lane, consume);
+      bf.push(part[1], 2 * p, lane, consume);
+      bf.push(part[2], 4 * p, lane, consume);
+    }
+  }
+  bf.flush(lane, consume);
+}
+
 // Wavefront argmax of (value, period): largest value, lowest period among equals
 // (the reference scans p upward with a strict '>', Periods.py:512).  period 0 = none.
 __device__ __forceinline__ void wave_argmax(double& v, int& p) {

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
                                                       int chunks, unsigned flags, Tables tb,
-                                                      const PGeom* __restrict__ geom, double* __restrict__ out) {
+                                                      const PGeom* __restrict__ geom,
+                                                      const PassPlan* __restrict__ plan, int n_pass,
+                                                      double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* xs = cv.take<T>(N + kPad);
@@ -142,7 +144,10 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         if ((lane & 7) == 0) orow[p - p_lo] = v;
       });
     } else {
-      wave_sweep<T, false>(xs, N, geom, pa + wv, pb, nw, lane, [&](double v, int p) {
+      // norm modes: the workgroups of a window split the pass plan, not the period range
+      const int pper = (n_pass + chunks - 1) / chunks;
+      const int i0 = c * pper, i1 = min(n_pass, i0 + pper);
+      wave_sweep_plan<T>(xs, N, geom, plan, i0 + wv, i1, nw, lane, [&](double v, int p) {
         if ((lane & 7) == 0) orow[p - p_lo] = periodic_norm_from_sq(v, N, mode == 1 ? p : 0);
       });
     }
@@ -162,6 +167,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
                                                         const PGeom* __restrict__ geom,
+                                                        const PassPlan* __restrict__ plan, int n_pass,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, T* __restrict__ bases_out,
                                                         double* __restrict__ dnorm_out,
@@ -210,10 +216,11 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     double best = 0.0;
     int bestp = 0;
     if (!general) {
-      wave_sweep<T, false>(work, N, geom, p_lo + wv, p_hi, nw, lane, [&](double ss, int p) {
+      // periods arrive out of order from the pass plan: keep the lowest period among equal norms
+      wave_sweep_plan<T>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
         const double v = periodic_norm_from_sq(ss, N, gamma ? p : 0);
         const bool skipped = (skip[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u;
-        if (v > best && !skipped) {
+        if (!skipped && (v > best || (v == best && bestp != 0 && p < bestp))) {
           best = v;
           bestp = p;
         }
