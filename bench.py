@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-root-leg", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,13 +141,17 @@ def main():
     from pyperiod_amd.synth import multi_sinusoid_batch
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # == local_rank on a full node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    eng = PeriodEngine(local_rank)
+    eng = PeriodEngine(dev_index)
     # windows rank*1024 .. rank*1024+1023 of the seeded generator; resident in HBM before t0
     x_host = multi_sinusoid_batch(rank * WINDOWS_PER_GPU, WINDOWS_PER_GPU, N_SAMPLES)
     x = torch.from_numpy(x_host).to(dev)
