@@ -764,39 +764,35 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   if (q_lo < 1 || q_hi < 1) return fail(PH_E_ARG, "need q_lo, q_hi >= 1 (got %d, %d)", q_lo, q_hi);
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  const int nw = kBlock / 64;
-  size_t lds = carve_bytes(N, sz) + 3 * carve_bytes((size_t)nw * q_hi, 8);
+  const int nw = ph::kRamBlock / 64;
+  size_t lds = carve_bytes(N + kPad, sz) + carve_bytes((size_t)nw * q_hi, 8);
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
-  // integer tables: Moebius mu, Euler phi, and for every q the divisors d with mu(q/d) != 0
-  std::vector<int32_t> mu(q_hi + 1, 1), phi(q_hi + 1), off(q_hi + 2, 0), dd, dm;
+  const ph::PGeom* geom;
+  PH_TRY(prepare_geom(c, N, q_hi, &geom));
+  // integer tables: Euler phi and, for every q, q / r for each prime r | q
+  std::vector<int32_t> phi(q_hi + 1), off(q_hi + 2, 0), dd;
   {
-    std::vector<char> comp(q_hi + 1, 0);
     for (int i = 0; i <= q_hi; ++i) phi[i] = i;
+    std::vector<std::vector<int32_t>> primes_of(q_hi + 1);
+    std::vector<char> comp(q_hi + 1, 0);
     for (int i = 2; i <= q_hi; ++i) {
       if (comp[i]) continue;
       for (int j = i; j <= q_hi; j += i) {
         comp[j] = j > i;
-        mu[j] = -mu[j];
         phi[j] -= phi[j] / i;
+        primes_of[j].push_back(i);
       }
-      const int64_t sq = (int64_t)i * i;
-      for (int64_t j = sq; j <= q_hi; j += sq) mu[j] = 0;
     }
-    for (int q = 1; q <= q_hi; ++q) {
+    for (int q = 0; q <= q_hi; ++q) {
       off[q] = (int32_t)dd.size();
-      for (int d = 1; d <= q; ++d)
-        if (q % d == 0 && mu[q / d] != 0) {
-          dd.push_back(d);
-          dm.push_back(mu[q / d]);
-        }
+      for (int r : primes_of[q]) dd.push_back(q / r);
     }
-    off[0] = 0;
     off[q_hi + 1] = (int32_t)dd.size();
+    if (dd.empty()) dd.push_back(1);
   }
-  const int *d_off, *d_d, *d_mu, *d_phi;
+  const int *d_off, *d_d, *d_phi;
   PH_TRY(upload_table(c, T_AUX0, off.data(), off.size(), &d_off));
   PH_TRY(upload_table(c, T_AUX1, dd.data(), dd.size(), &d_d));
-  PH_TRY(upload_table(c, T_AUX2, dm.data(), dm.size(), &d_mu));
   PH_TRY(upload_table(c, T_AUX3, phi.data(), phi.size(), &d_phi));
   Stage st(c, flags);
   const void* dx;
@@ -810,15 +806,15 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
       PH_TRY(allow_lds(ph::k_ramanujan<double>, lds));
       {
         ProfScope ps_(c, "k_ramanujan");
-        hipLaunchKernelGGL(ph::k_ramanujan<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, q_lo,
-                           q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+        hipLaunchKernelGGL(ph::k_ramanujan<double>, grid, dim3(ph::kRamBlock), lds, c->stream, (const double*)dx, N,
+                           q_lo, q_hi, geom, d_off, d_d, d_phi, (double*)dout);
       }
     } else {
       PH_TRY(allow_lds(ph::k_ramanujan<float>, lds));
       {
         ProfScope ps_(c, "k_ramanujan");
-        hipLaunchKernelGGL(ph::k_ramanujan<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, q_lo,
-                           q_hi, d_off, d_d, d_mu, d_phi, (double*)dout);
+        hipLaunchKernelGGL(ph::k_ramanujan<float>, grid, dim3(ph::kRamBlock), lds, c->stream, (const float*)dx, N,
+                           q_lo, q_hi, geom, d_off, d_d, d_phi, (double*)dout);
       }
     }
     PH_TRY(launch_check("k_ramanujan"));

@@ -695,67 +695,123 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 //   Rows of the reference dictionary are shifts of c_q / phi(q) (the row / max(row) at :129
 //   cancels the L2 normalisation of :168).  With S = fold of x to period q:
 //     a = S (star) c_q / phi,  out = a (*) c_q / phi  ==  (q/phi)^2 * E_q S,
-//   where E_q = sum_{d | q} mu(q/d) * (mean over the q/d cosets mod d) is the projector onto
-//   the Ramanujan subspace; norms[q] = sum_j cnt_q[j] * out_j^2.  wave-per-q; div tables
-//   (d, mu(q/d)) per q come from the host side of the library.
+//   where E_q = sum_{d | q} mu(q/d) P_d = prod_{prime r | q} (I - P_{q/r}) is the projector onto
+//   the Ramanujan subspace (P_d = mean over the q/d cosets mod d), and
+//   norms[q] = sum_j cnt_q[j] * out_j^2.
+//   wave-per-q: the fold uses the chunked wave fold (S_q lands in a per-wave LDS strip), the
+//   projector is applied in place, one prime factor at a time.  16 waves share one window.
 // ======================================================================================
+constexpr int kRamBlock = 1024;
+
+template <typename T, int C, int U>
+__device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0,
+                                                 int lane, double* __restrict__ sbuf) {
+  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
+  double s[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) s[c] = 0.0;
+  fold_rows<T, C, U>((lds_ptr)xs + lane + 64 * c0, p, rows - 1, s);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = 64 * (c0 + c) + lane;
+    const bool has = j < nfull;
+    const T v = xs[has ? (rows - 1) * p + j : 0];
+    if (j < p) sbuf[j] = s[c] + (has ? (double)v : 0.0);
+  }
+}
+
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_ramanujan(const T* __restrict__ x, int N, int q_lo, int q_hi,
-                                                      const int* __restrict__ div_off,
-                                                      const int* __restrict__ div_d,
-                                                      const int* __restrict__ div_mu,
-                                                      const int* __restrict__ totient,
-                                                      double* __restrict__ out) {
+__global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x, int N, int q_lo, int q_hi,
+                                                         const PGeom* __restrict__ geom,
+                                                         const int* __restrict__ pr_off,
+                                                         const int* __restrict__ pr_d,
+                                                         const int* __restrict__ totient,
+                                                         double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = cv.take<T>(N);
+  T* xs = cv.take<T>(N + kPad);
   const int nw = blockDim.x >> 6;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
-  double* sbuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // S_q
-  double* obuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // filtered
-  double* fbuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // fold of S to d
+  double* sbuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // this wave's S_q
 
   const int64_t w = blockIdx.x;
   load_window(x + w * (int64_t)N, xs, N);
+  zero_pad(xs, N);
   double* orow = out + w * (int64_t)(q_hi + 1);
-  for (int q = threadIdx.x; q < q_lo && q <= q_hi; q += blockDim.x) orow[q] = 0.0;
   __syncthreads();
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
 
   for (int q = q_lo + wv; q <= q_hi; q += nw) {
-    const Fold f(N, q);
-    for (int j = lane; j < q; j += kWave) {
-      sbuf[j] = (double)column_sum(xs, j, q, f.count(j));
-      obuf[j] = 0.0;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int k = div_off[q]; k < div_off[q + 1]; ++k) {
-      const int d = div_d[k];
-      const double coef = (double)div_mu[k] * (double)d / (double)q;
-      const int reps = q / d;
-      for (int i = lane; i < d; i += kWave) {
-        double s = 0.0;
-        for (int r = 0; r < reps; ++r) s += sbuf[i + r * d];
-        fbuf[i] = s * coef;
+    const int rows = geom[q].rows, nfull = geom[q].nfull;
+    // ---- S_q[j] = sum_{n = j (mod q)} x[n]
+    if (q >= 64) {
+      const int nchunks = (q + 63) >> 6;
+      int c0 = 0;
+      for (; c0 + 4 <= nchunks; c0 += 4) fold_store_group<T, 4, 2>(xs, q, rows, nfull, c0, lane, sbuf);
+      switch (nchunks - c0) {
+        case 3: fold_store_group<T, 3, 2>(xs, q, rows, nfull, c0, lane, sbuf); break;
+        case 2: fold_store_group<T, 2, 4>(xs, q, rows, nfull, c0, lane, sbuf); break;
+        case 1: fold_store_group<T, 1, 8>(xs, q, rows, nfull, c0, lane, sbuf); break;
+        default: break;
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (int j = lane; j < q; j += kWave) obuf[j] += fbuf[j % d];
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else {
+      // q < 64: G = 64/q row groups fill the wavefront, partials combined with G shuffles
+      const int G = 64 / q, L = G * q, full = N / L;
+      const bool on = lane < L;
+      const T* ptr = xs + (on ? lane : 0);
+      double s0 = 0.0, s1 = 0.0;
+      int r = 0;
+      for (; r + 4 <= full; r += 4) {
+        const T a = ptr[0], b = ptr[L], c = ptr[2 * L], d = ptr[3 * L];
+        s0 += (double)a;
+        s1 += (double)b;
+        s0 += (double)c;
+        s1 += (double)d;
+        ptr += 4 * L;
+      }
+      for (; r < full; ++r) {
+        s0 += (double)ptr[0];
+        ptr += L;
+      }
+      const bool tail = on && (full * L + lane < N);
+      const T tv = xs[tail ? full * L + lane : 0];
+      double part = s0 + s1 + (tail ? (double)tv : 0.0);
+      part = on ? part : 0.0;
+      const int j = lane % q;
+      double tot = 0.0;
+      for (int gi = 0; gi < G; ++gi) tot += __shfl(part, j + gi * q, kWave);
+      if (lane < q) sbuf[lane] = tot;
     }
+    wave_sync();
+    // ---- E_q in place: for every prime r | q subtract the mean over the r cosets mod q/r
+    for (int k = pr_off[q]; k < pr_off[q + 1]; ++k) {
+      const int d = pr_d[k];  // q / r
+      const int r = q / d;
+      const double inv_r = 1.0 / (double)r;
+      for (int i = lane; i < d; i += kWave) {
+        double m = 0.0;
+        for (int t = 0; t < r; ++t) m += sbuf[i + t * d];
+        m *= inv_r;
+        for (int t = 0; t < r; ++t) sbuf[i + t * d] -= m;
+      }
+      wave_sync();
+    }
+    // ---- norms[q] = sum_j cnt_j ((q/phi)^2 (E_q S)_j)^2
     const double scale = (double)q / (double)totient[q];
     const double s2 = scale * scale;
     double acc = 0.0;
     for (int j = lane; j < q; j += kWave) {
-      const double o = obuf[j] * s2;
-      acc += (double)f.count(j) * o * o;
+      const double o = sbuf[j] * s2;
+      acc += (double)(j < nfull ? rows : rows - 1) * o * o;
     }
     acc = wave_sum(acc);
     if (lane == 0) orow[q] = acc;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    wave_sync();
   }
 }
 
