@@ -165,6 +165,21 @@ int ph_ramanujan_norms(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, 
 int ph_dict_project(ph_ctx* ctx, const double* x, const double* basis, int rows, int N,
                     unsigned flags, float* out);
 
+/* ---- QOPeriods.find_periods, non-orthogonal / update_weights=True branch -----------------
+ * (QOPeriods.py:373-596, get_subspaces :830-840, solve_quadratic :779-796) with the default
+ * test function rms(reconstruction) > rms(data) * thresh.  The whole greedy loop runs on the
+ * device, one workgroup per window: gamma sweep, phi-mass row bookkeeping, Gram matrix and
+ * right-hand side by folds, Cholesky solve, reconstruction, residual.
+ * periods/norms/keeps (W, num): dictionary blocks in the order found (period, gamma norm, rows
+ * kept); counts (W, 2) = {periods the reference reports, blocks in the dictionary} (they differ
+ * by one when the test function stopped the loop, QOPeriods.py:584-592); weights (W, kcap)
+ * float64, rows of block b start at sum(keeps[:b]); residual (W, N) dtype of x.
+ * kcap = capacity in dictionary rows per window (status PH_ST_CAP when exceeded). */
+int ph_qo_find_periods(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int num,
+                       double thresh, int min_length, int max_length, int kcap, unsigned flags,
+                       uint32_t* periods, double* norms, int32_t* keeps, int32_t* counts,
+                       double* weights, void* residual, int32_t* status);
+
 /* ---- QOPeriods building blocks (QOPeriods.py:779-795) -----------------------------------
  * ph_fold_sums: W = A x for natural-basis rows -- out[w, off_k + j] = sum_{n = j (mod p_k)}
  * x[w, n], j < keep_k; row stride = sum(keep).  ph_tile_sum: reconstruction A^T w --

@@ -2,12 +2,15 @@
 
 Mirrors the reference surface (pyPeriod/QOPeriods.py:148-1310).  The v1 reference class cannot
 even be constructed (QOPeriods.py:190) and only its non-orthogonal ``find_periods`` branch runs
-(SURVEY.md section 0); that branch is what is implemented here, with the heavy pieces on the GPU:
+(SURVEY.md section 0); that branch is what is implemented here:
 
-  * the gamma-normalised all-p sweep over the residual      -> ph_sweep          (QOPeriods.py:470-478)
-  * W = A x and A' = A A^T for natural-basis rows            -> ph_fold_sums      (QOPeriods.py:781-782)
-  * reconstruction A^T w                                     -> ph_tile_sum       (QOPeriods.py:795)
-  * the small dense solve A' w = W stays on host LAPACK, as in the reference (QOPeriods.py:794).
+  * plain projection, default test function: the whole greedy loop (gamma sweep, phi-mass row
+    bookkeeping, Gram matrix and right-hand side by folds, Cholesky solve, reconstruction,
+    residual) runs in ONE kernel launch per window batch -> ph_qo_find_periods
+  * other settings (custom test_function, update_weights=False, trunc, window, Ramanujan basis):
+    the loop is driven from the host with the heavy pieces on the GPU -- the sweep (ph_sweep,
+    QOPeriods.py:470-478), W = A x and A A^T as folds (ph_fold_sums, :781-782), A^T w
+    (ph_tile_sum, :795) -- and the small dense solve on host LAPACK like the reference (:794).
 """
 
 from __future__ import annotations
@@ -109,6 +112,19 @@ class QOPeriods(Periods):
             )
 
         eng = default_engine()
+        plain = (
+            update_weights
+            and "test_function" not in kwargs
+            and thresh is not None
+            and not self._trunc_to_integer_multiple
+            and self._basis_type == "natural"
+            and (self.window is None or self.window is False)
+        )
+        if plain:
+            # the whole greedy loop in one kernel launch (ph_qo_find_periods)
+            done = self._find_periods_device(eng, data, N, num, thresh, min_length, max_length)
+            if done is not None:
+                return done
         reconstruction = None
         nonzero_periods = periods[:0]
         for i in range(num):
@@ -165,6 +181,35 @@ class QOPeriods(Periods):
                 self._output_bases = output_bases
                 break
         return (output_bases, res)
+
+    def _find_periods_device(self, eng, data, N, num, thresh, min_length, max_length):
+        """Assemble the reference's return value from the device loop's compact outputs."""
+        kcap = 512
+        while True:
+            per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(
+                data[None, :], num, thresh, min_length, max_length, kcap
+            )
+            if st[0] == _ffi.PH_ST_CAP and kcap < 2048:
+                kcap *= 2
+                continue
+            break
+        if st[0] != _ffi.PH_ST_OK:
+            return None  # dictionary larger than the device workspace: host-driven loop below
+        n_report, n_blocks = int(counts[0, 0]), int(counts[0, 1])
+        if n_blocks == 0:
+            return None
+        blocks = [(int(per[0, b]), int(keeps[0, b])) for b in range(n_blocks)]
+        basis_dictionary = {str(q): k for q, k in blocks}
+        basis_matricies = np.vstack([self.Pp(q, N, k, self._basis_type) for q, k in blocks])
+        output_bases = {
+            "periods": per[0, :n_report].copy(),
+            "norms": nrm[0, :n_report].copy(),
+            "subspaces": basis_matricies,
+            "weights": wts[0, : basis_matricies.shape[0]].copy(),
+            "basis_dictionary": basis_dictionary,
+        }
+        self._output_bases = output_bases
+        return (output_bases, resid[0].copy())
 
     def _solve_structured(self, x, basis_matrix, dictionary):
         """solve_quadratic for a natural-basis dictionary without touching the dense matrix

@@ -54,7 +54,7 @@ struct TableSlot {
 };
 
 enum { T_PLIST, T_ORTH_OFF, T_ORTH_Q, T_FAC_OFF, T_FAC_Q, T_AUX0, T_AUX1, T_AUX2, T_AUX3, T_COUNT };
-enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_COUNT };
+enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_GEN0, B_COUNT };
 
 }  // namespace
 
@@ -971,6 +971,87 @@ int ph_dict_project(ph_ctx* c, const double* x, const double* basis, int rows, i
     PH_HIP(hipStreamSynchronize(c->stream));
   }
   return PH_OK;
+}
+
+// ----------------------------------------------------------------------------- QOPeriods.find_periods
+int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, double thresh,
+                       int min_length, int max_length, int kcap, unsigned flags, uint32_t* periods,
+                       double* norms, int32_t* keeps, int32_t* counts, double* weights, void* residual,
+                       int32_t* status) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!periods || !norms || !keeps || !counts || !weights || !residual || !status)
+    return fail(PH_E_ARG, "output pointer is NULL");
+  if (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH))
+    return fail(PH_E_UNSUPPORTED, "ph_qo_find_periods implements the plain-projection branch only");
+  if (num < 1) return fail(PH_E_ARG, "num=%d must be >= 1", num);
+  if (max_length < 0) max_length = N / 3;  // QOPeriods.py:374-375
+  if (min_length < 1 || max_length < min_length)
+    return fail(PH_E_ARG, "need 1 <= min_length <= max_length (got %d, %d)", min_length, max_length);
+  if (kcap < 1 || kcap > 2048) return fail(PH_E_ARG, "kcap=%d must be in [1, 2048]", kcap);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  size_t lds = carve_bytes(N + kPad, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+               carve_bytes(kMaxWaves, 4) + 2 * carve_bytes(ph::kQoMaxBlocks, 4) +
+               carve_bytes(ph::kQoMaxBlocks + 1, 4) + carve_bytes(ph::kQoMaxBlocks, 8) +
+               carve_bytes((max_length + 32) / 32, 4) + carve_bytes(kcap, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_qo_find_periods"));
+  const ph::PGeom* geom;
+  PH_TRY(prepare_geom(c, N, max_length, &geom));
+  const ph::PassPlan* plan;
+  int n_pass;
+  PH_TRY(prepare_plan(c, min_length, max_length, &plan, &n_pass));
+  // Euler phi and all divisors of every candidate period (QOPeriods.py:834-838)
+  std::vector<int32_t> phi(max_length + 1), off(max_length + 2, 0), dq;
+  for (int i = 0; i <= max_length; ++i) phi[i] = i;
+  for (int i = 2; i <= max_length; ++i)
+    if (phi[i] == i)
+      for (int j = i; j <= max_length; j += i) phi[j] -= phi[j] / i;
+  for (int q = 0; q <= max_length; ++q) {
+    off[q] = (int32_t)dq.size();
+    for (int d = 1; q > 0 && d <= q; ++d)
+      if (q % d == 0) dq.push_back(d);
+  }
+  off[max_length + 1] = (int32_t)dq.size();
+  if (dq.empty()) dq.push_back(1);
+  const int *d_phi, *d_off, *d_dq;
+  PH_TRY(upload_table(c, T_AUX0, phi.data(), phi.size(), &d_phi));
+  PH_TRY(upload_table(c, T_AUX1, off.data(), off.size(), &d_off));
+  PH_TRY(upload_table(c, T_AUX2, dq.data(), dq.size(), &d_dq));
+  const size_t ws_per = 2 * (size_t)kcap * kcap + 2 * (size_t)kcap;
+  PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * ws_per * sizeof(double)));
+  Stage st(c, flags);
+  const void* dx;
+  void *dper, *dnrm, *dkeep, *dcnt, *dwts, *dres, *dstat;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, periods, (size_t)W * num * sizeof(uint32_t), &dper));
+  PH_TRY(st.out(B_OUT1, norms, (size_t)W * num * sizeof(double), &dnrm));
+  PH_TRY(st.out(B_OUT2, keeps, (size_t)W * num * sizeof(int32_t), &dkeep));
+  PH_TRY(st.out(B_OUT3, counts, (size_t)W * 2 * sizeof(int32_t), &dcnt));
+  PH_TRY(st.out(B_OUT4, weights, (size_t)W * kcap * sizeof(double), &dwts));
+  PH_TRY(st.out(B_WS0, residual, (size_t)W * N * sz, &dres));
+  PH_TRY(st.out(B_GEN0, status, (size_t)W * sizeof(int32_t), &dstat));
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_qo_find<double>, lds));
+    {
+      ProfScope ps_(c, "k_qo_find");
+      hipLaunchKernelGGL(ph::k_qo_find<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, num,
+                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap,
+                         (double*)c->buf[B_WS1].p, (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt,
+                         (double*)dwts, (double*)dres, (int*)dstat);
+    }
+  } else {
+    PH_TRY(allow_lds(ph::k_qo_find<float>, lds));
+    {
+      ProfScope ps_(c, "k_qo_find");
+      hipLaunchKernelGGL(ph::k_qo_find<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, num,
+                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap,
+                         (double*)c->buf[B_WS1].p, (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt,
+                         (double*)dwts, (float*)dres, (int*)dstat);
+    }
+  }
+  PH_TRY(launch_check("k_qo_find"));
+  return st.finish();
 }
 
 }  // extern "C"

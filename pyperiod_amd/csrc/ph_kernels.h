@@ -861,6 +861,239 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 }
 
 // ======================================================================================
+// QOPeriods.find_periods, non-orthogonal / update_weights=True branch (QOPeriods.py:373-596
+// with :468-478, :510-522, :560-594; get_subspaces :830-840; solve_quadratic :779-796), the
+// whole greedy loop on the device.  One workgroup per window.  Per iteration:
+//   gamma-normalised all-p sweep of the residual (pass plan)  -> strongest period
+//   rows kept for it = Euler-phi mass its divisors add to the running divisor set
+//   Gram matrix A A^T extended by the new rows (integer co-occurrence counts, by folding the
+//   indicator rows), right-hand side extended by the fold of the data
+//   Cholesky solve in the window's HBM workspace, reconstruction A^T w, residual
+// The reference stops when rms(reconstruction) <= rms(data) * thresh (default test_function)
+// or when numpy.linalg.solve raises LinAlgError (here: a non-positive Cholesky pivot, a period
+// that adds no new rows, or a repeated period -- the cases that make the reference's matrix
+// singular).  counts[w] = {periods reported, blocks in the dictionary}.
+// ======================================================================================
+constexpr int kQoMaxBlocks = 64;
+
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
+                                                        int p_lo, int p_hi, const PGeom* __restrict__ geom,
+                                                        const PassPlan* __restrict__ plan, int n_pass,
+                                                        const int* __restrict__ phi, const int* __restrict__ div_off,
+                                                        const int* __restrict__ div_q, int kcap,
+                                                        double* __restrict__ ws_all, uint32_t* __restrict__ periods_out,
+                                                        double* __restrict__ norms_out, int* __restrict__ keeps_out,
+                                                        int* __restrict__ counts_out, double* __restrict__ weights_out,
+                                                        T* __restrict__ resid_out, int* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* work = cv.take<T>(N + kPad);  // the residual
+  double* red = cv.take<double>(kRedDoubles);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  int* bper = cv.take<int>(kQoMaxBlocks);       // period of dictionary block b
+  int* bkeep = cv.take<int>(kQoMaxBlocks);      // rows kept for it
+  int* boff = cv.take<int>(kQoMaxBlocks + 1);   // first row of block b
+  double* bnorm = cv.take<double>(kQoMaxBlocks);
+  uint32_t* seen = cv.take<uint32_t>((p_hi + 32) / 32);  // running divisor set R (QOPeriods.py:832-835)
+  double* yv = cv.take<double>(kcap);  // solve vector
+
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const T* data = x + w * (int64_t)N;
+  double* G = ws_all + w * (2 * (int64_t)kcap * kcap + 2 * (int64_t)kcap);  // Gram, column-major, ld = kcap
+  double* L = G + (int64_t)kcap * kcap;                                      // Cholesky factor
+  double* rhs = L + (int64_t)kcap * kcap;
+  double* wts = rhs + kcap;  // last good weights
+
+  load_window(data, work, N);
+  zero_pad(work, N);
+  for (int k = tid; k < (p_hi + 32) / 32; k += blockDim.x) seen[k] = 0u;
+  if (tid == 0) boff[0] = 0;
+  __syncthreads();
+  const double data_sq = block_sumsq(work, N, red);
+  double recon_sq = 0.0;
+  int nb = 0;        // blocks in the dictionary
+  int status = 0;
+  bool stopped_by_test = false;
+
+  for (int it = 0; it < num; ++it) {
+    if (it > 0 && !(sqrt(recon_sq / N) > sqrt(data_sq / N) * thresh)) {  // QOPeriods.py:391,418
+      stopped_by_test = true;
+      break;
+    }
+    if (nb >= kQoMaxBlocks) {
+      status = 3;
+      break;
+    }
+    // ---- strongest gamma-normalised projection of the residual (QOPeriods.py:470-478)
+    double best = 0.0;
+    int bestp = 0;
+    wave_sweep_plan<T>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
+      const double v = periodic_norm_from_sq(ss, N, p);
+      if (v > best || (v == best && bestp != 0 && p < bestp)) {
+        best = v;
+        bestp = p;
+      }
+    });
+    wave_argmax(best, bestp);
+    if (lane == 0) {
+      wbest[wv] = best;
+      wbestp[wv] = bestp;
+    }
+    __syncthreads();
+    best = 0.0;
+    bestp = 0;
+    for (int i = 0; i < nw; ++i) {
+      const double v = wbest[i];
+      const int pp = wbestp[i];
+      if (pp != 0 && (v > best || (v == best && pp < bestp))) {
+        best = v;
+        bestp = pp;
+      }
+    }
+    __syncthreads();
+    if (bestp == 0) break;  // nothing left to explain; the reference keeps looping on zeros
+    // ---- rows this period contributes (QOPeriods.py:833-840); a repeated period or one whose
+    //      divisors are all present adds none and makes the reference's matrix singular
+    int keep = 0;
+    for (int k = div_off[bestp]; k < div_off[bestp + 1]; ++k) {
+      const int r = div_q[k];
+      if (!((seen[r >> 5] >> (r & 31)) & 1u)) keep += phi[r];
+    }
+    bool repeated = false;
+    for (int b = 0; b < nb; ++b) repeated |= (bper[b] == bestp);
+    __syncthreads();
+    const int row0 = boff[nb];
+    if (keep == 0 || repeated) break;  // LinAlgError path (QOPeriods.py:552-559)
+    if (row0 + keep > kcap) {
+      status = 3;
+      break;
+    }
+    if (tid == 0) {
+      for (int k = div_off[bestp]; k < div_off[bestp + 1]; ++k) seen[div_q[k] >> 5] |= 1u << (div_q[k] & 31);
+      bper[nb] = bestp;
+      bkeep[nb] = keep;
+      boff[nb + 1] = row0 + keep;
+      bnorm[nb] = best;
+    }
+    __syncthreads();
+    const int K = row0 + keep;
+    // ---- Gram rows of the new block: G[(a,i),(nb,j)] = #{n < N : n = i (mod p_a), n = j (mod p)}
+    for (int j = tid; j < keep; j += blockDim.x) {
+      double* col = G + (int64_t)(row0 + j) * kcap;  // column (nb, j); thread j owns it
+      for (int r = 0; r < K; ++r) col[r] = 0.0;
+      for (int b = 0; b <= nb; ++b) {
+        const int pa = bper[b], ka = bkeep[b], oa = boff[b];
+        int i = j % pa;
+        const int step = bestp % pa;
+        for (int n = j; n < N; n += bestp) {
+          if (i < ka) col[oa + i] += 1.0;
+          i += step;
+          if (i >= pa) i -= pa;
+        }
+      }
+      // right-hand side: fold of the data (QOPeriods.py:782), rows in order
+      double s = 0.0;
+      for (int n = j; n < N; n += bestp) s += (double)data[n];
+      rhs[row0 + j] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // mirror the new columns into the old columns' new rows
+    for (int e = tid; e < row0 * keep; e += blockDim.x) {
+      const int r = e % row0, j = e / row0;
+      G[(int64_t)r * kcap + (row0 + j)] = G[(int64_t)(row0 + j) * kcap + r];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- Cholesky G = L L^T (lower, column-major), then L y = rhs, L^T w = y
+    for (int e = tid; e < K * K; e += blockDim.x) {
+      const int r = e % K, cidx = e / K;
+      if (r >= cidx) L[(int64_t)cidx * kcap + r] = G[(int64_t)cidx * kcap + r];
+    }
+    __threadfence_block();
+    __syncthreads();
+    bool singular = false;
+    for (int k = 0; k < K; ++k) {
+      const double piv = L[(int64_t)k * kcap + k];
+      if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
+        singular = true;
+        break;
+      }
+      const double d = sqrt(piv);
+      __syncthreads();
+      for (int r = k + tid; r < K; r += blockDim.x) L[(int64_t)k * kcap + r] /= d;
+      __threadfence_block();
+      __syncthreads();
+      // trailing update: column c (> k) -= L[c][k] * L[:, k]
+      const int rem = K - k - 1;
+      for (int e = tid; e < rem * rem; e += blockDim.x) {
+        const int cc = k + 1 + e / rem, rr = k + 1 + e % rem;
+        if (rr >= cc) L[(int64_t)cc * kcap + rr] -= L[(int64_t)k * kcap + rr] * L[(int64_t)k * kcap + cc];
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (singular) break;  // go back one iteration and stop (QOPeriods.py:552-559)
+    // L y = rhs, then L^T w = y: column sweeps, the vector lives in LDS
+    for (int r = tid; r < K; r += blockDim.x) yv[r] = rhs[r];
+    __syncthreads();
+    for (int cidx = 0; cidx < K; ++cidx) {
+      const double yc = yv[cidx] / L[(int64_t)cidx * kcap + cidx];
+      __syncthreads();
+      for (int r = cidx + 1 + tid; r < K; r += blockDim.x) yv[r] -= L[(int64_t)cidx * kcap + r] * yc;
+      if (tid == 0) yv[cidx] = yc;
+      __syncthreads();
+    }
+    for (int cidx = K - 1; cidx >= 0; --cidx) {
+      const double wc = yv[cidx] / L[(int64_t)cidx * kcap + cidx];
+      __syncthreads();
+      for (int r = tid; r < cidx; r += blockDim.x) yv[r] -= L[(int64_t)r * kcap + cidx] * wc;
+      if (tid == 0) yv[cidx] = wc;
+      __syncthreads();
+    }
+    nb += 1;
+    // ---- reconstruction A^T w (QOPeriods.py:795) and the new residual
+    double rs = 0.0;
+    for (int n = tid; n < N; n += blockDim.x) {
+      double rec = 0.0;
+      for (int b = 0; b < nb; ++b) {
+        const int i = n % bper[b];
+        if (i < bkeep[b]) rec += yv[boff[b] + i];
+      }
+      rs += rec * rec;
+      work[n] = (T)((double)data[n] - rec);
+    }
+    for (int r = tid; r < K; r += blockDim.x) wts[r] = yv[r];
+    recon_sq = block_sum(rs, red);
+    __syncthreads();
+  }
+  __syncthreads();
+  // outputs.  When the loop stopped on the test function the reference reports all periods
+  // but the last one, yet keeps the weights / dictionary of all of them (QOPeriods.py:584-592).
+  const int n_report = stopped_by_test ? nb - 1 : nb;
+  for (int b = tid; b < num; b += blockDim.x) {
+    const bool in = b < nb;
+    periods_out[w * num + b] = in ? (uint32_t)bper[b] : 0u;
+    norms_out[w * num + b] = in ? bnorm[b] : 0.0;
+    keeps_out[w * num + b] = in ? bkeep[b] : 0;
+  }
+  const int Kf = boff[nb];
+  for (int r = tid; r < kcap; r += blockDim.x) weights_out[w * (int64_t)kcap + r] = r < Kf ? wts[r] : 0.0;
+  for (int n = tid; n < N; n += blockDim.x) resid_out[w * (int64_t)N + n] = work[n];
+  if (tid == 0) {
+    counts_out[2 * w] = n_report < 0 ? 0 : n_report;
+    counts_out[2 * w + 1] = nb;
+    status_out[w] = status;
+  }
+}
+
+// ======================================================================================
 // Periods.periodic_norm over a batch (Periods.py:221-241); streams from HBM, any N.
 // ======================================================================================
 template <typename T>

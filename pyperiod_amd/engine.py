@@ -301,6 +301,31 @@ class PeriodEngine:
             _ffi.check(self._lib.ph_dict_project(self._ctx, x.ctypes.data, basis.ctypes.data, basis.shape[0], x.size, 0, out.ctypes.data))
         return out
 
+    def qo_find_periods(self, x, num, thresh, min_length=2, max_length=None, kcap=512):
+        """QOPeriods.find_periods (plain projection, update_weights=True, default test function)
+        for a batch.  -> periods (W,num) u32, norms (W,num), keeps (W,num) i32, counts (W,2) i32,
+        weights (W,kcap) f64, residual (W,N), status (W)."""
+        x, code, W, N, fl, mk = self._prep(x)
+        if max_length is None:
+            max_length = N // 3
+        num = int(num)
+        periods = mk.empty((W, num), np.uint32)
+        norms = mk.empty((W, num), np.float64)
+        keeps = mk.empty((W, num), np.int32)
+        counts = mk.empty((W, 2), np.int32)
+        weights = mk.empty((W, int(kcap)), np.float64)
+        resid = mk.empty((W, N), self._np_dtype(code))
+        status = mk.empty((W,), np.int32)
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_qo_find_periods(
+                    self._ctx, mk.addr(x), code, W, N, num, float(thresh), int(min_length), int(max_length), int(kcap),
+                    fl, mk.addr(periods), mk.addr(norms), mk.addr(keeps), mk.addr(counts), mk.addr(weights),
+                    mk.addr(resid), mk.addr(status),
+                )
+            )
+        return periods, norms, keeps, counts, weights, resid, status
+
     def fold_sums(self, x, p_list, keep):
         """W = A x for natural-basis rows (QOPeriods.py:782): (W, sum(keep)) float64."""
         x, code, W, N, fl, mk = self._prep(x)

@@ -294,6 +294,29 @@ def test_qoperiods_matches_reference_golden(eng, golden):
         assert rel_err(res, g[f"fp_{tag}_residual"]) < 1e-8
 
 
+def test_qoperiods_device_loop_batch_vs_oracle(eng, golden):
+    """ph_qo_find_periods: the whole greedy loop on the device, a batch of windows per launch."""
+    g = golden("qoperiods")
+    x = multi_sinusoid_batch(5, 1, 1536)
+    per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(x, 4, 0.2, 4, 200)
+    assert st[0] == 0
+    nrep, nb = counts[0]
+    assert np.array_equal(per[0, :nrep], g["fp_w5_periods"]) and rel_err(nrm[0, :nrep], g["fp_w5_norms"]) < TOL
+    assert list(keeps[0, :nb]) == list(g["fp_w5_dict_vals"]) and list(per[0, :nb]) == list(g["fp_w5_dict_keys"])
+    k = int(keeps[0, :nb].sum())
+    assert rel_err(wts[0, :k], g["fp_w5_weights"]) < 1e-8 and rel_err(resid[0], g["fp_w5_residual"]) < 1e-8
+    xb = multi_sinusoid_batch(70, 6, 900)
+    per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(xb, 5, 0.1, 2, None)
+    for w in range(6):
+        out, res = po.qo_find_periods(xb[w], 5, 0.1)
+        nrep, nb = counts[w]
+        assert np.array_equal(per[w, :nrep], out["periods"]), w
+        assert rel_err(nrm[w, :nrep], out["norms"]) < TOL
+        assert list(keeps[w, :nb]) == list(out["basis_dictionary"].values())
+        k = int(keeps[w, :nb].sum())
+        assert rel_err(wts[w, :k], out["weights"]) < 1e-8 and rel_err(resid[w], res) < 1e-8
+
+
 # ------------------------------------------------------------------------------ class surface
 def test_class_surface_matches_reference_behaviour(eng):
     from pyperiod_amd import Periods

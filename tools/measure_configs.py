@@ -39,7 +39,7 @@ def timed(fn, reps=3):
     return out, wall, kern
 
 
-which = sys.argv[1:] or ["c2host", "sweep", "c4", "c3", "bc", "k1"]
+which = sys.argv[1:] or ["c2host", "sweep", "c4", "c3", "bc", "k1", "c5"]
 
 if "c2host" in which or "sweep" in which or "bc" in which or "k1" in which:
     xh = multi_sinusoid_batch(0, 1024, 4096)
@@ -73,4 +73,11 @@ if "c3" in which:
     _, wall, kern = timed(lambda: eng.ramanujan_norms(x3, 2, 512), 2)
     ms = kern["k_ramanujan"]
     res["c3_ramanujan_1024x8192_q512"] = {"ms": ms, "window_q_per_s": W * 511 / (ms * 1e-3), "logical_GBs": W * 511 * 65536 / (ms * 1e-3) / 1e9}
+if "c5" in which:
+    W = 512
+    x5 = torch.from_numpy(multi_sinusoid_batch(0, W, 16384, dtype=np.float32)).to(dev)
+    out, wall, kern = timed(lambda: eng.qo_find_periods(x5, 3, 0.1, 8, 300, 1024), 2)
+    ms = kern["k_qo_find"]
+    res["c5_qo_find_periods_512x16384_fp32"] = {"ms": ms, "windows_per_s": W / (ms * 1e-3), "mean_blocks": float(out[3][:, 1].double().mean().item()),
+                                                "mean_rows": float(out[2].double().sum(1).mean().item())}
 print(json.dumps(res, indent=1))
