@@ -72,6 +72,7 @@ struct ph_ctx {
   int geom_n = -1, geom_max_p = -1;
   DevBuf plan;  // pass plan of the norm sweeps, cached for the last (p_lo, p_hi)
   int plan_lo = -1, plan_hi = -1, plan_n = 0;
+  int plan_max_m = 4;  // largest row-class count a pass may use (PH_PLAN_MAX_M overrides: 1, 2 or 4)
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
@@ -139,7 +140,8 @@ int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n
       continue;
     }
     if (covered[p]) continue;
-    const int m = (4LL * p <= p_hi) ? 4 : (2LL * p <= p_hi) ? 2 : 1;
+    int m = (4LL * p <= p_hi) ? 4 : (2LL * p <= p_hi) ? 2 : 1;
+    m = std::min(m, c->plan_max_m);
     for (int d = 1; d <= m; d *= 2) covered[(size_t)d * p] = 1;
     host.push_back(ph::PassPlan{p, m});
   }
@@ -383,6 +385,10 @@ int ph_create(int device, ph_ctx** out) {
     return fail(PH_E_HIP, "stream/event creation: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("PH_PLAN_MAX_M")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4) c->plan_max_m = v;
+  }
   if (const char* e = std::getenv("PH_SWEEP_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 512 && v % 64 == 0) c->sweep_block = v;
