@@ -404,9 +404,24 @@ __device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, i
   return (lane < p) ? tot * tot * w : 0.0;
 }
 
+#ifndef PH_SEGMENTED
+#define PH_SEGMENTED 1
+#endif
+template <typename T, int M, bool MAXABS>
+__device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
+                                              int lane, double (&part)[3]);
+
 template <typename T, bool MAXABS>
 __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, int p, const PGeom& g, int lane) {
+#if PH_SEGMENTED
+  if (p >= 64) {
+    double part[3];
+    wave_pass_seg<T, 1, MAXABS>(xs, p, &g - p, lane, part);  // &g == geom + p
+    return part[0];
+  }
+#else
   if (p >= 64) return wave_partial_large<T, MAXABS>(xs, p, g, lane);
+#endif
   return MAXABS ? wave_partial_small_maxabs(xs, p, g, lane) : wave_partial_small(xs, N, p, g, lane);
 }
 
@@ -577,6 +592,140 @@ __device__ __forceinline__ void wave_pass(const T* __restrict__ xs, int p, const
   if (c0 < nchunks) pass_group<T, M, 1>(xs, p, rows, nfull, c0, lane, dg, part);
 }
 
+// ---------------------------------------------------------------- segmented passes
+// For a base period p every count boundary of every produced period (p, 2p, 4p) falls on the
+// same base residue: nfull_q - u p = N - k p for some integer k, and the only such value strictly
+// inside (0, p) is c = N mod p.  Splitting the base residues into segment A = [0, c) and
+// segment B = [c, p) therefore makes everything wave-uniform inside a segment: the number of
+// rows a residue owns (R in A, R-1 in B) and the count weight of every produced residue class.
+// No per-lane classification is left in the fold; only the last chunk of a segment masks the
+// lanes past its end.
+//
+// seg_group: C chunks of 64 consecutive base residues starting at `base`; rows are added in
+// blocks of U (U = M for M >= 2; row class u = r mod M); a[u][c] keeps row-order sums.
+// acc layout: [0] period p, [1..2] period 2p (u = 0, 1), [3..6] period 4p (u = 0..3);
+// wgt holds the matching scalar weights of this segment.
+template <typename T, int M, int U, int C, bool MAXABS, bool MASK>
+__device__ __forceinline__ void seg_group(const volatile __attribute__((address_space(3))) T* ptr, int p, int nrows,
+                                          int nvalid, int lane, const double (&wgt)[7], double (&part)[3]) {
+  static_assert(U % M == 0, "a row block must cover whole class cycles");
+  double a[M][C];
+#pragma unroll
+  for (int u = 0; u < M; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) a[u][c] = 0.0;
+  int r = 0;
+  for (; r + U <= nrows; r += U) {
+    T v[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wait per block, see fold_rows
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u % M][c] += (double)v[u][c];
+    ptr += U * p;
+  }
+  if (U > 1) {  // fewer than U rows left; their classes continue the cycle (r is a multiple of M)
+    const int rem = nrows - r;
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) {
+      if (u < rem) {
+        // keep this a real (wave-uniform) branch: hipcc otherwise if-converts it into two
+        // v_cndmask per accumulator on every group
+        asm volatile("" ::: "memory");
+        T v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = ptr[u * p + 64 * c];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[u % M][c] += (double)v[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    if (MASK) {  // last group of the segment: lanes past its end hold garbage
+#pragma unroll
+      for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : 0.0;
+    }
+    if (M == 1) {
+      const double t = a[0][c];
+      part[0] = MAXABS ? fmax(part[0], fabs(t)) : fma(t, t * wgt[0], part[0]);
+    } else if (M == 2) {
+      const double e = a[0][c], o = a[1 % M][c], t = e + o;
+      part[0] = fma(t, t * wgt[0], part[0]);
+      part[1] = fma(e, e * wgt[1], part[1]);
+      part[1] = fma(o, o * wgt[2], part[1]);
+    } else {
+      const double e = a[0][c] + a[2 % M][c], o = a[1 % M][c] + a[3 % M][c], t = e + o;
+      part[0] = fma(t, t * wgt[0], part[0]);
+      part[1] = fma(e, e * wgt[1], part[1]);
+      part[1] = fma(o, o * wgt[2], part[1]);
+#pragma unroll
+      for (int u = 0; u < M; ++u) part[2] = fma(a[u][c], a[u][c] * wgt[3 + u], part[2]);
+    }
+  }
+}
+
+// Per-lane partials of ||P_q x||^2 for q = p (M >= 1), 2p (M >= 2), 4p (M == 4) -- or of
+// max_s |S_p[s]| (MAXABS, M == 1, row-order sums) -- for a base period p >= 64.
+template <typename T, int M, bool MAXABS>
+__device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
+                                              int lane, double (&part)[3]) {
+  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
+  constexpr int U = (M == 1) ? 2 : M;
+  constexpr int CM = (M == 4) ? 2 : 4;
+  const int rows = geom[p].rows, cut = geom[p].nfull;  // residues < cut own `rows` samples
+  int qn[3];
+  double qf[3], qs[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int q = (t == 0 || (t == 1 && M >= 2) || M == 4) ? (p << t) : p;
+    qn[t] = geom[q].nfull;
+    qf[t] = geom[q].w_full;
+    qs[t] = geom[q].w_short;
+    part[t] = 0.0;
+  }
+#pragma unroll 1
+  for (int seg = 0; seg < 2; ++seg) {
+    const int start = seg == 0 ? 0 : cut;
+    const int len = seg == 0 ? cut : p - cut;
+    if (len <= 0) continue;
+    const int nrows = seg == 0 ? rows : rows - 1;
+    double wgt[7];  // weight of residue class (t, u) in this segment: uniform, see above
+    wgt[0] = start < qn[0] ? qf[0] : qs[0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wgt[1 + u] = (start + u * p < qn[1]) ? qf[1] : qs[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wgt[3 + u] = (start + u * p < qn[2]) ? qf[2] : qs[2];
+    const lds_ptr base = (lds_ptr)xs + start + lane;
+    const int nchunks = (len + 63) >> 6;
+    int c0 = 0;
+    const int whole = len >> 6;  // chunks whose 64 residues all belong to the segment
+    for (; c0 + CM <= whole; c0 += CM)
+      seg_group<T, M, U, CM, MAXABS, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
+    if (CM == 4) {
+      switch (nchunks - c0) {
+        case 4: seg_group<T, M, U, 4, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 3: seg_group<T, M, U, 3, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 2: seg_group<T, M, U, 2, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: seg_group<T, M, U, 1, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        default: break;
+      }
+    } else {
+      switch (nchunks - c0) {
+        case 2: seg_group<T, M, U, 2, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: seg_group<T, M, U, 1, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        default: break;
+      }
+    }
+  }
+}
+
 // The online 8-period butterfly of wave_sweep as a state machine, for producers that deliver
 // one to three periods at a time.  `k` is wave-uniform.
 struct Butterfly8 {
@@ -632,12 +781,20 @@ __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N,
       bf.push(wave_partial<T, false>(xs, N, p, geom[p], lane), p, lane, consume);
     } else if (m == 2) {
       double part[3];
+#if PH_SEGMENTED
+      wave_pass_seg<T, 2, false>(xs, p, geom, lane, part);
+#else
       wave_pass<T, 2>(xs, p, geom, lane, part);
+#endif
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
     } else {
       double part[3];
+#if PH_SEGMENTED
+      wave_pass_seg<T, 4, false>(xs, p, geom, lane, part);
+#else
       wave_pass<T, 4>(xs, p, geom, lane, part);
+#endif
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
       bf.push(part[2], 4 * p, lane, consume);
