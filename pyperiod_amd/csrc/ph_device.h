@@ -431,13 +431,54 @@ __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, 
 // rolled -- one copy of the fold code in the instruction cache -- and at most three partials
 // are pending.  Afterwards lane L holds the full value of period slot
 // bit5(L) + 2 bit4(L) + 4 bit3(L) of the block.
+// Cross-lane moves for doubles on gfx950 without the LDS crossbar (ds_bpermute):
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows of two registers,
+// DPP moves data inside a row of 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i inside each group of 8
+constexpr int kDppRor8 = 0x128;        // row_ror 8: lane i <- lane i ^ 8 inside a row of 16
+
+// One butterfly level: `lo` and `hi` are per-lane partials of two different periods (or period
+// groups).  Afterwards the lanes whose bit `mask` is clear hold lo summed over the lane pair
+// (l, l ^ mask) and the lanes whose bit is set hold hi summed over the pair.
 template <bool MAXABS>
 __device__ __forceinline__ double butterfly_merge(double lo, double hi, int mask, int lane) {
-  const bool up = lane & mask;
+  auto op = [](double x, double y) { return MAXABS ? fmax(x, y) : x + y; };
+  if (mask == 32 || mask == 16) {
+    unsigned l0 = (unsigned)__double2loint(lo), l1 = (unsigned)__double2hiint(lo);
+    unsigned h0 = (unsigned)__double2loint(hi), h1 = (unsigned)__double2hiint(hi);
+    if (mask == 32) {
+      const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
+      l0 = r0[0]; h0 = r0[1]; l1 = r1[0]; h1 = r1[1];
+    } else {
+      const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
+      l0 = r0[0]; h0 = r0[1]; l1 = r1[0]; h1 = r1[1];
+    }
+    return op(__hiloint2double((int)l1, (int)l0), __hiloint2double((int)h1, (int)h0));
+  }
+  const bool up = lane & mask;  // mask == 8
   const double keep = up ? hi : lo;
   const double send = up ? lo : hi;
-  const double got = __shfl_xor(send, mask, kWave);
-  return MAXABS ? fmax(keep, got) : keep + got;
+  return op(keep, dpp_f64<kDppRor8>(send));
+}
+
+// All-reduce inside every group of 8 consecutive lanes (three DPP steps).
+template <bool MAXABS>
+__device__ __forceinline__ double reduce8(double v) {
+  auto op = [](double x, double y) { return MAXABS ? fmax(x, y) : x + y; };
+  v = op(v, dpp_f64<kDppHalfMirror>(v));
+  v = op(v, dpp_f64<kDppXor1>(v));
+  v = op(v, dpp_f64<kDppXor2>(v));
+  return v;
 }
 
 __device__ __forceinline__ int butterfly8_slot(int lane) {
@@ -472,11 +513,7 @@ __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, cons
       }
       tot = butterfly_merge<MAXABS>(l3, a, 8, lane);
     }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-      const double got = __shfl_xor(tot, o, kWave);
-      tot = MAXABS ? fmax(tot, got) : tot + got;
-    }
+    tot = reduce8<MAXABS>(tot);
     const int p = pb + butterfly8_slot(lane) * stride;
     if (p <= p_hi) consume(tot, p);
   }
@@ -652,14 +689,14 @@ __device__ __forceinline__ void seg_group(const volatile __attribute__((address_
 #pragma unroll
       for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : 0.0;
     }
-    if (M == 1) {
+    if (M == 1) {  // M <= 2: plain sums of squares per class, weighted once per segment
       const double t = a[0][c];
-      part[0] = MAXABS ? fmax(part[0], fabs(t)) : fma(t, t * wgt[0], part[0]);
+      part[0] = MAXABS ? fmax(part[0], fabs(t)) : fma(t, t, part[0]);
     } else if (M == 2) {
       const double e = a[0][c], o = a[1 % M][c], t = e + o;
-      part[0] = fma(t, t * wgt[0], part[0]);
-      part[1] = fma(e, e * wgt[1], part[1]);
-      part[1] = fma(o, o * wgt[2], part[1]);
+      part[0] = fma(t, t, part[0]);
+      part[1] = fma(e, e, part[1]);
+      part[2] = fma(o, o, part[2]);
     } else {
       const double e = a[0][c] + a[2 % M][c], o = a[1 % M][c] + a[3 % M][c], t = e + o;
       part[0] = fma(t, t * wgt[0], part[0]);
@@ -675,7 +712,7 @@ __device__ __forceinline__ void seg_group(const volatile __attribute__((address_
 // max_s |S_p[s]| (MAXABS, M == 1, row-order sums) -- for a base period p >= 64.
 template <typename T, int M, bool MAXABS>
 __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
-                                              int lane, double (&part)[3]) {
+                                              int lane, double (&total)[3]) {
   typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
   constexpr int U = (M == 1) ? 2 : M;
   constexpr int CM = (M == 4) ? 2 : 4;
@@ -688,7 +725,7 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
     qn[t] = geom[q].nfull;
     qf[t] = geom[q].w_full;
     qs[t] = geom[q].w_short;
-    part[t] = 0.0;
+    total[t] = 0.0;
   }
 #pragma unroll 1
   for (int seg = 0; seg < 2; ++seg) {
@@ -706,6 +743,8 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
     const int nchunks = (len + 63) >> 6;
     int c0 = 0;
     const int whole = len >> 6;  // chunks whose 64 residues all belong to the segment
+    double sacc[3] = {0.0, 0.0, 0.0};
+    double(&part)[3] = (M <= 2) ? sacc : total;
     for (; c0 + CM <= whole; c0 += CM)
       seg_group<T, M, U, CM, MAXABS, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
     if (CM == 4) {
@@ -722,6 +761,12 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
         case 1: seg_group<T, M, U, 1, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         default: break;
       }
+    }
+    if (M == 1) {
+      total[0] = MAXABS ? fmax(total[0], sacc[0]) : fma(sacc[0], wgt[0], total[0]);
+    } else if (M == 2) {
+      total[0] = fma(sacc[0], wgt[0], total[0]);
+      total[1] = fma(sacc[1], wgt[1], fma(sacc[2], wgt[2], total[1]));
     }
   }
 }
@@ -750,9 +795,7 @@ struct Butterfly8 {
         if ((k & 4) == 0) {
           l3 = a;
         } else {
-          double tot = butterfly_merge<false>(l3, a, 8, lane);
-#pragma unroll
-          for (int o = 4; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+          const double tot = reduce8<false>(butterfly_merge<false>(l3, a, 8, lane));
           if (myp != 0) consume(tot, myp);
           myp = 0;
         }
