@@ -216,15 +216,34 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     double best = 0.0;
     int bestp = 0;
     if (!general) {
-      // periods arrive out of order from the pass plan: keep the lowest period among equal norms
+      // Periods arrive out of order from the pass plan.  The reference compares the rounded norms
+      // sqrt(ss)/sqrt(N)[/sqrt(p)] and keeps the lowest period among equal ones (Periods.py:512);
+      // the norm is monotone in ss (ss / p in gamma mode), so the sums of squares are compared
+      // directly and the square roots and divisions are evaluated only when two candidates are
+      // within rounding distance of each other -- and once per lane at the end.
+      double best_ss = 0.0;
       wave_sweep_plan<T>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
-        const double v = periodic_norm_from_sq(ss, N, gamma ? p : 0);
         const bool skipped = (skip[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u;
-        if (!skipped && (v > best || (v == best && bestp != 0 && p < bestp))) {
-          best = v;
+        if (skipped || !(ss > 0.0)) return;
+        bool take = bestp == 0;
+        if (!take) {
+          const double lhs = gamma ? ss * (double)bestp : ss;
+          const double rhs = gamma ? best_ss * (double)p : best_ss;
+          if (lhs > rhs * (1.0 + 1e-14)) {
+            take = true;
+          } else if (lhs >= rhs * (1.0 - 1e-14)) {
+            const double vn = periodic_norm_from_sq(ss, N, gamma ? p : 0);
+            const double vb = periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0);
+            take = vn > vb || (vn == vb && p < bestp);
+          }
+        }
+        if (take) {
+          best_ss = ss;
           bestp = p;
         }
       });
+      best = bestp != 0 ? periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0) : 0.0;
+      if (!(best > 0.0)) bestp = 0;  // the reference needs p_norm > 0 (Periods.py:497,512)
       wave_argmax(best, bestp);
       if (lane == 0) {
         wbest[wv] = best;
@@ -933,13 +952,26 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     // ---- strongest gamma-normalised projection of the residual (QOPeriods.py:470-478)
     double best = 0.0;
     int bestp = 0;
+    double best_ss = 0.0;  // same lazy comparison as in k_mbest_step1 (gamma norm: ss / p)
     wave_sweep_plan<T>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
-      const double v = periodic_norm_from_sq(ss, N, p);
-      if (v > best || (v == best && bestp != 0 && p < bestp)) {
-        best = v;
+      if (!(ss > 0.0)) return;
+      bool take = bestp == 0;
+      if (!take) {
+        const double lhs = ss * (double)bestp, rhs = best_ss * (double)p;
+        if (lhs > rhs * (1.0 + 1e-14)) {
+          take = true;
+        } else if (lhs >= rhs * (1.0 - 1e-14)) {
+          const double vn = periodic_norm_from_sq(ss, N, p), vb = periodic_norm_from_sq(best_ss, N, bestp);
+          take = vn > vb || (vn == vb && p < bestp);
+        }
+      }
+      if (take) {
+        best_ss = ss;
         bestp = p;
       }
     });
+    best = bestp != 0 ? periodic_norm_from_sq(best_ss, N, bestp) : 0.0;
+    if (!(best > 0.0)) bestp = 0;
     wave_argmax(best, bestp);
     if (lane == 0) {
       wbest[wv] = best;
