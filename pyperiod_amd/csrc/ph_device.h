@@ -2,14 +2,17 @@
 //
 // Everything here works on ONE signal window that is resident in LDS.  A window-projection
 // (Periods.project, reference Periods.py:142-219) is a strided fold -> mean -> tile; it has
-// no dense contraction, so there is no MFMA anywhere in this library.  The two mappings are
+// no dense contraction, so there is no MFMA anywhere in this library.  The mappings are
 //   * thread-per-residue, rows accumulated in order r = 0..R-1: bit-identical to the
 //     reference's np.sum(cp, 0) (Periods.py:194).  Used wherever a projection is
-//     materialised (bases, residual updates) and for max|S_p[s]|.
-//   * wave-per-period: one 64-lane wavefront owns a candidate period p, lanes own residues,
-//     consecutive lanes read consecutive LDS words (conflict-free ds_read_b64), squared
-//     sums are combined with wavefront shuffles.  Used by the norm sweeps, where the
-//     reference's own norm (BLAS ddot inside np.linalg.norm) has no defined order.
+//     materialised (bases, residual updates).
+//   * wave-per-period passes (seg_group / wave_pass_seg): one 64-lane wavefront owns a base
+//     period p, lanes own residues, consecutive lanes read consecutive LDS words
+//     (conflict-free ds_read_b64).  The base residues are split at N mod p, which makes the row
+//     count and every count weight wave-uniform; one pass can also yield the folds of 2p and
+//     4p (row classes).  Eight periods are reduced across lanes with permlane swaps and DPP.
+//     Used by the sweeps, where the reference's own norm (BLAS ddot inside np.linalg.norm)
+//     has no defined order; the max|S| sweep keeps row-order sums (bit-identical).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -189,30 +192,6 @@ __device__ __forceinline__ double periodic_norm_from_sq(double ss, int N, int p_
   return v;
 }
 
-// ---------------------------------------------------------------- wave-per-period fold
-// ||P_p x||^2 = sum_j S_p[j]^2 / cnt_p[j] for the plain projection.  The two
-// count classes are accumulated separately so the hot loop has no division.
-// Returns the value in every lane of the calling wavefront.
-template <typename T>
-__device__ __forceinline__ double wave_proj_sq(const T* __restrict__ xs, int N, int p, int lane) {
-  const Fold f(N, p);
-  double acc_full = 0.0, acc_short = 0.0;
-  for (int j = lane; j < p; j += kWave) {
-    const bool full = j < f.nfull;
-    const int n = full ? f.rows : f.rows - 1;
-    const double s = (double)column_sum(xs, j, p, n);
-    if (full)
-      acc_full += s * s;
-    else
-      acc_short += s * s;
-  }
-  acc_full = wave_sum(acc_full);
-  acc_short = wave_sum(acc_short);
-  double v = acc_full / (double)f.rows;
-  if (f.rows > 1) v += acc_short / (double)(f.rows - 1);
-  return v;
-}
-
 // ---------------------------------------------------------------- tuned wave-per-period fold
 // Per-period geometry, built once on the host for (N, p) and read with scalar loads: the hot
 // loop has no integer or floating-point division.
@@ -223,13 +202,8 @@ struct PGeom {
   double w_short;  // 1 / (R-1)   (0 when R == 1)
 };
 
-constexpr int kPad = 512;  // LDS windows are followed by kPad zeroed elements (see fold_group)
-
-// Accumulators of one period: squared sums of the residues that own R samples (`full`) and
-// R-1 samples (`shrt`), or the running max |S| in MAXABS mode (kept in `full`).
-struct FoldAcc {
-  double full = 0.0, shrt = 0.0;
-};
+constexpr int kPad = 256;  // LDS windows are followed by kPad zeroed elements: a 4-chunk group reads up to
+                           // 255 elements past the last row of the window (see seg_group)
 
 // s[c] += sum over `nrows` rows of the C chunks starting at `ptr` (row stride p).  U rows x C
 // chunks of independent ds_read_b64 are issued back to back, then ONE lgkmcnt(0) (the scalar
@@ -266,98 +240,6 @@ __device__ __forceinline__ void fold_rows(const volatile __attribute__((address_
       ptr += p;
     }
   }
-}
-
-// One group of C consecutive 64-residue chunks of period p; lane owns residues
-// 64 (c0 + c) + lane.  Whether all residues of the group own R samples, all own R-1, or the
-// group straddles nfull / p is wave-uniform; only one or two groups per period take the
-// general path.  Lanes whose residue is >= p read at most 64 C - 1 elements past a row --
-// inside the window or its zeroed kPad tail -- and are discarded by a select.
-template <typename T, int C, int U, bool MAXABS>
-__device__ __forceinline__ void fold_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
-                                           FoldAcc& acc) {
-  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
-  double s[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) s[c] = 0.0;
-  const lds_ptr base = (lds_ptr)xs + lane + 64 * c0;
-  const int jlo = 64 * c0, jhi = jlo + 64 * C;
-  const bool all_full = jhi <= nfull;                 // every residue of the group owns R samples
-  const bool all_short = jlo >= nfull && jhi <= p;    // every residue owns R-1 samples
-  fold_rows<T, C, U>(base, p, all_full ? rows : rows - 1, s);
-  if (all_full || all_short) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (MAXABS)
-        acc.full = fmax(acc.full, fabs(s[c]));
-      else if (all_full)
-        acc.full = fma(s[c], s[c], acc.full);
-      else
-        acc.shrt = fma(s[c], s[c], acc.shrt);
-    }
-  } else {
-    // the group straddles nfull and/or p: classify chunk by chunk (still wave-uniform); at most
-    // two chunks of a period need the per-lane selects
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int j0 = jlo + 64 * c;
-      if (j0 + 64 <= nfull) {
-        const double t = s[c] + (double)base[(rows - 1) * p + 64 * c];
-        acc.full = MAXABS ? fmax(acc.full, fabs(t)) : fma(t, t, acc.full);
-      } else if (j0 >= nfull && j0 + 64 <= p) {
-        if (MAXABS)
-          acc.full = fmax(acc.full, fabs(s[c]));
-        else
-          acc.shrt = fma(s[c], s[c], acc.shrt);
-      } else if (j0 < p) {
-        const int j = j0 + lane;
-        const bool has = j < nfull;
-        const T v = xs[has ? (rows - 1) * p + j : 0];
-        const double t = (j < p) ? s[c] + (has ? (double)v : 0.0) : 0.0;
-        if (MAXABS) {
-          acc.full = fmax(acc.full, fabs(t));
-        } else {
-          const double tf = has ? t : 0.0, ts = has ? 0.0 : t;
-          acc.full = fma(tf, tf, acc.full);
-          acc.shrt = fma(ts, ts, acc.shrt);
-        }
-      }
-    }
-  }
-}
-
-// Per-lane partial of ||P_p x||^2 (or of max|S|) for p >= 64; the wavefront reduction of the
-// returned values is the result.
-template <typename T, bool MAXABS>
-__device__ __forceinline__ double wave_partial_large(const T* __restrict__ xs, int p, const PGeom& gref, int lane) {
-  // copy the geometry out of memory once (the caller's stores could alias it otherwise)
-  const int rows = gref.rows, nfull = gref.nfull;
-  const double w_full = gref.w_full, w_short = gref.w_short;
-  const int nchunks = (p + 63) >> 6;
-  FoldAcc acc;
-  int c0 = 0;
-#ifndef PH_MAIN_C8
-#define PH_MAIN_C8 0
-#endif
-#ifndef PH_C4_U
-#define PH_C4_U 2
-#endif
-#if PH_MAIN_C8
-  for (; c0 + 8 <= nchunks; c0 += 8) fold_group<T, 8, 1, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
-  if (c0 + 4 <= nchunks) {
-    fold_group<T, 4, PH_C4_U, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
-    c0 += 4;
-  }
-#else
-  for (; c0 + 4 <= nchunks; c0 += 4) fold_group<T, 4, PH_C4_U, MAXABS>(xs, p, rows, nfull, c0, lane, acc);
-#endif
-  switch (nchunks - c0) {
-    case 3: fold_group<T, 3, 2, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
-    case 2: fold_group<T, 2, 4, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
-    case 1: fold_group<T, 1, 8, MAXABS>(xs, p, rows, nfull, c0, lane, acc); break;
-    default: break;
-  }
-  return MAXABS ? acc.full : acc.full * w_full + acc.shrt * w_short;
 }
 
 // p < 64, max|S| mode: one lane per residue, rows in order (bit-identical sums).
@@ -404,24 +286,17 @@ __device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, i
   return (lane < p) ? tot * tot * w : 0.0;
 }
 
-#ifndef PH_SEGMENTED
-#define PH_SEGMENTED 1
-#endif
 template <typename T, int M, bool MAXABS>
 __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
                                               int lane, double (&part)[3]);
 
 template <typename T, bool MAXABS>
 __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, int p, const PGeom& g, int lane) {
-#if PH_SEGMENTED
   if (p >= 64) {
     double part[3];
     wave_pass_seg<T, 1, MAXABS>(xs, p, &g - p, lane, part);  // &g == geom + p
     return part[0];
   }
-#else
-  if (p >= 64) return wave_partial_large<T, MAXABS>(xs, p, g, lane);
-#endif
   return MAXABS ? wave_partial_small_maxabs(xs, p, g, lane) : wave_partial_small(xs, N, p, g, lane);
 }
 
@@ -529,105 +404,6 @@ struct PassPlan {
   int p;  // base period
   int m;  // 1, 2 or 4: the pass yields p, 2p (m >= 2) and 4p (m == 4); 0: p < 64, row-split path
 };
-
-struct DerivedGeom {  // count classes of a produced period q
-  int nfull;
-  double w_full, w_short;
-};
-
-template <typename T, int M, int C>
-__device__ __forceinline__ void pass_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0, int lane,
-                                           const DerivedGeom (&dg)[3], double (&part)[3]) {
-  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
-  double a[M][C];  // a[u][c]: rows r = u (mod M) of residue 64 (c0 + c) + lane
-#pragma unroll
-  for (int u = 0; u < M; ++u)
-#pragma unroll
-    for (int c = 0; c < C; ++c) a[u][c] = 0.0;
-  lds_ptr ptr = (lds_ptr)xs + lane + 64 * c0;
-  const int full_rows = rows - 1;  // rows every residue owns
-  const int nblk = full_rows / M;
-  for (int b = 0; b < nblk; ++b) {
-    T v[M][C];
-#pragma unroll
-    for (int u = 0; u < M; ++u)
-#pragma unroll
-      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see fold_rows
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < M; ++u)
-#pragma unroll
-      for (int c = 0; c < C; ++c) a[u][c] += (double)v[u][c];
-    ptr += M * p;
-  }
-  // tail block: rows nblk M + u exist in full for u < rem; row u == rem is the ragged last row
-  const int rem = full_rows - nblk * M;
-#pragma unroll
-  for (int u = 0; u < M; ++u) {
-    if (u < rem) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) a[u][c] += (double)ptr[u * p + 64 * c];
-    } else if (u == rem) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const int j = 64 * (c0 + c) + lane;
-        const bool has = j < nfull;
-        const T t = xs[has ? full_rows * p + j : 0];
-        a[u][c] += has ? (double)t : 0.0;
-      }
-    }
-  }
-  auto emit = [&](int t, int i, double val) {
-    const double w = (i < dg[t].nfull) ? dg[t].w_full : dg[t].w_short;
-    part[t] = fma(val, val * w, part[t]);
-  };
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const int j = 64 * (c0 + c) + lane;
-    if (64 * (c0 + c) + 64 > p) {  // the chunk that contains p: lanes past the period hold garbage
-#pragma unroll
-      for (int u = 0; u < M; ++u) a[u][c] = (j < p) ? a[u][c] : 0.0;
-    }
-    if (M == 2) {
-      emit(0, j, a[0][c] + a[1][c]);
-      emit(1, j, a[0][c]);
-      emit(1, j + p, a[1][c]);
-    } else {
-      const double e = a[0][c] + a[2 % M][c], o = a[1][c] + a[3 % M][c];
-      emit(0, j, e + o);
-      emit(1, j, e);
-      emit(1, j + p, o);
-#pragma unroll
-      for (int u = 0; u < M; ++u) emit(2, j + u * p, a[u][c]);
-    }
-  }
-}
-
-// Per-lane partials of ||P_q x||^2 for q = p, 2p (and 4p when M == 4); p >= 64.
-template <typename T, int M>
-__device__ __forceinline__ void wave_pass(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom, int lane,
-                                          double (&part)[3]) {
-  const int rows = geom[p].rows, nfull = geom[p].nfull;
-  DerivedGeom dg[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int q = (t == 0 || (t == 1) || M == 4) ? (p << t) : p;
-    dg[t].nfull = geom[q].nfull;
-    dg[t].w_full = geom[q].w_full;
-    dg[t].w_short = geom[q].w_short;
-    part[t] = 0.0;
-  }
-  const int nchunks = (p + 63) >> 6;
-  constexpr int CM = (M == 4) ? 2 : 4;
-  int c0 = 0;
-  for (; c0 + CM <= nchunks; c0 += CM) pass_group<T, M, CM>(xs, p, rows, nfull, c0, lane, dg, part);
-  if (CM == 4 && c0 + 2 <= nchunks) {
-    pass_group<T, M, 2>(xs, p, rows, nfull, c0, lane, dg, part);
-    c0 += 2;
-  }
-  if (c0 < nchunks) pass_group<T, M, 1>(xs, p, rows, nfull, c0, lane, dg, part);
-}
 
 // ---------------------------------------------------------------- segmented passes
 // For a base period p every count boundary of every produced period (p, 2p, 4p) falls on the
@@ -824,20 +600,12 @@ __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N,
       bf.push(wave_partial<T, false>(xs, N, p, geom[p], lane), p, lane, consume);
     } else if (m == 2) {
       double part[3];
-#if PH_SEGMENTED
       wave_pass_seg<T, 2, false>(xs, p, geom, lane, part);
-#else
-      wave_pass<T, 2>(xs, p, geom, lane, part);
-#endif
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
     } else {
       double part[3];
-#if PH_SEGMENTED
       wave_pass_seg<T, 4, false>(xs, p, geom, lane, part);
-#else
-      wave_pass<T, 4>(xs, p, geom, lane, part);
-#endif
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
       bf.push(part[2], 4 * p, lane, consume);
@@ -858,18 +626,6 @@ __device__ __forceinline__ void wave_argmax(double& v, int& p) {
       p = op;
     }
   }
-}
-
-// max_s |S_p[s]| with row-order sums (Periods.py:327-331), in every lane.
-template <typename T>
-__device__ __forceinline__ double wave_fold_maxabs(const T* __restrict__ xs, int N, int p, int lane) {
-  const Fold f(N, p);
-  double best = 0.0;
-  for (int j = lane; j < p; j += kWave) {
-    const double s = fabs((double)column_sum(xs, j, p, f.count(j)));
-    best = fmax(best, s);
-  }
-  return wave_max(best);
 }
 
 // Workgroup-cooperative value of one sweep entry for any flag combination (slow path):
