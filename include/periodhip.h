@@ -180,6 +180,13 @@ int ph_qo_find_periods(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, 
                        uint32_t* periods, double* norms, int32_t* keeps, int32_t* counts,
                        double* weights, void* residual, int32_t* status);
 
+/* ---- QOPeriods.get_best_period_orthogonal / eq_3 / auto_corr (QOPeriods.py:1122-1232) -----
+ * powers (W, max_p) float64: the Muresan-Parks orthogonal period powers `pows` for q < max_p
+ * (entry 0 is 0), divided by q when normalize != 0; autocorr (W, N) = auto_corr(x, k) for every
+ * lag k, eq3 (W, max_p) = eq_3(x, q) -- both optional (NULL).  max_p < 0 = floor(N/2). */
+int ph_orth_powers(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int max_p,
+                   int normalize, unsigned flags, double* autocorr, double* eq3, double* powers);
+
 /* ---- QOPeriods building blocks (QOPeriods.py:779-795) -----------------------------------
  * ph_fold_sums: W = A x for natural-basis rows -- out[w, off_k + j] = sum_{n = j (mod p_k)}
  * x[w, n], j < keep_k; row stride = sum(keep).  ph_tile_sum: reconstruction A^T w --

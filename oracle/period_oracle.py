@@ -506,3 +506,48 @@ def qo_find_periods(data, num, thresh, min_length=2, max_length=None):
             }
             break
     return out, res
+
+
+# --------------------------------------------------------------------------------------
+# Orthogonal period powers  (QOPeriods.py:1122-1232)
+# --------------------------------------------------------------------------------------
+
+
+def auto_corr(x, k: int) -> float:
+    """QOPeriods.auto_corr (:1151-1173)."""
+    n = len(x)
+    return np.sum(x[0 : n - k] * x[k:n])
+
+
+def eq_3(x, p: int) -> float:
+    """QOPeriods.eq_3 (:1122-1149)."""
+    n = len(x)
+    second = 0
+    for l in range(1, n // p):
+        second += auto_corr(x, int(l * p))
+    return (p / n) * (auto_corr(x, 0) + 2 * second)
+
+
+def orth_powers(x, max_p=None, normalize=False) -> np.ndarray:
+    """get_best_period_orthogonal(..., return_powers=True) (:1175-1225)."""
+    if max_p is None:
+        max_p = len(x) // 2
+    q_all = np.arange(1, max_p)
+    pows = np.zeros(q_all[-1] + 1)
+    for q in q_all:
+        pows[q] = max(eq_3(x, int(q)), 0)
+        for f in factor_set(int(q)):
+            if f != q:
+                pows[q] -= pows[f]
+    pows[pows < 0] = 0
+    if normalize:
+        pows[1:] = pows[1:] / q_all
+    return pows
+
+
+def best_period_orthogonal(x, max_p=None, normalize=False) -> int:
+    """get_best_period_orthogonal(..., return_powers=False) (:1226-1232)."""
+    pows = orth_powers(x, max_p, normalize)
+    k = int(np.argmax(pows))
+    return k if k > 0 else 1
+

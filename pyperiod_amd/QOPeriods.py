@@ -352,6 +352,29 @@ class QOPeriods(Periods):
         vec = np.tile(np.roll(ramanujan_sum(q).astype(np.float64), s), repetitions)
         return vec.astype(complex) if type == "complex" else vec
 
+    # ------------------------------------------------------------------ orthogonal period powers
+    def auto_corr(self, x, k):
+        """sum_n x[n] x[n+k] (QOPeriods.py:1151-1173)."""
+        x = _as_window(x)
+        return np.float64(default_engine().orth_powers(x[None, :], 2, want_autocorr=True)[1][0, int(k)])
+
+    def eq_3(self, x, P):
+        """Equation 3 of Muresan & Parks (QOPeriods.py:1122-1149)."""
+        x = _as_window(x)
+        P = int(P)
+        return np.float64(default_engine().orth_powers(x[None, :], max(P + 1, 2), want_eq3=True)[1][0, P])
+
+    def get_best_period_orthogonal(self, x, max_p=None, normalize=False, return_powers=False):
+        """Strongest period by orthogonal (factor-subtracted) powers (QOPeriods.py:1175-1232)."""
+        x = _as_window(x)
+        if max_p is None:
+            max_p = len(x) // 2
+        pows = default_engine().orth_powers(x[None, :], int(max_p), normalize)[0]
+        if return_powers:
+            return pows
+        best = int(np.argmax(pows))
+        return best if best > 0 else 1  # Q[argmax] - 1 == argmax (QOPeriods.py:1227-1232)
+
     # ------------------------------------------------------------------ properties (QOPeriods.py:1237-1310)
     @property
     def basis_type(self):

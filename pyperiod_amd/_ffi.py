@@ -46,6 +46,7 @@ SIGNATURES = {
     "ph_ramanujan_norms": [_vp, _vp, _i, _i64, _i, _i, _i, _u, _vp],
     "ph_dict_project": [_vp, _vp, _vp, _i, _i, _u, _vp],
     "ph_qo_find_periods": [_vp, _vp, _i, _i64, _i, _i, _d, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ph_orth_powers": [_vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _vp, _vp],
     "ph_fold_sums": [_vp, _vp, _i, _i64, _i, _pi32, _pi32, _i, _u, _vp],
     "ph_tile_sum": [_vp, _vp, _i64, _i, _pi32, _pi32, _i, _i, _u, _vp],
 }

@@ -1060,4 +1060,68 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   return st.finish();
 }
 
+// ----------------------------------------------------------------------------- orthogonal period powers
+int ph_orth_powers(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int max_p, int normalize,
+                   unsigned flags, double* autocorr, double* eq3, double* powers) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!powers) return fail(PH_E_ARG, "powers is NULL");
+  if (max_p < 0) max_p = N / 2;  // QOPeriods.py:1204-1207
+  if (max_p < 2) return fail(PH_E_ARG, "max_p=%d must be >= 2", max_p);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  const size_t lds = carve_bytes(N, sz) + carve_bytes(N, 8) + carve_bytes(max_p, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_orth_powers"));
+  // divisors d of q with mu(q/d) != 0, for q < max_p
+  std::vector<int32_t> mu(max_p, 1), off(max_p + 1, 0), dd, dm;
+  {
+    std::vector<char> comp(max_p, 0);
+    for (int i = 2; i < max_p; ++i) {
+      if (comp[i]) continue;
+      for (int j = i; j < max_p; j += i) {
+        comp[j] = j > i;
+        mu[j] = -mu[j];
+      }
+      for (int64_t j = (int64_t)i * i; j < max_p; j += (int64_t)i * i) mu[j] = 0;
+    }
+    for (int q = 0; q < max_p; ++q) {
+      off[q] = (int32_t)dd.size();
+      for (int d = 1; q > 0 && d <= q; ++d)
+        if (q % d == 0 && mu[q / d] != 0) {
+          dd.push_back(d);
+          dm.push_back(mu[q / d]);
+        }
+    }
+    off[max_p] = (int32_t)dd.size();
+  }
+  const int *d_off, *d_d, *d_mu;
+  PH_TRY(upload_table(c, T_AUX0, off.data(), off.size(), &d_off));
+  PH_TRY(upload_table(c, T_AUX1, dd.data(), dd.size(), &d_d));
+  PH_TRY(upload_table(c, T_AUX2, dm.data(), dm.size(), &d_mu));
+  Stage st(c, flags);
+  const void* dx;
+  void *dr, *de, *dp;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, autocorr, (size_t)W * N * sizeof(double), &dr));
+  PH_TRY(st.out(B_OUT1, eq3, (size_t)W * max_p * sizeof(double), &de));
+  PH_TRY(st.out(B_OUT2, powers, (size_t)W * max_p * sizeof(double), &dp));
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_orth_powers<double>, lds));
+    {
+      ProfScope ps_(c, "k_orth_powers");
+      hipLaunchKernelGGL(ph::k_orth_powers<double>, grid, dim3(kBlockWide), lds, c->stream, (const double*)dx, N, max_p,
+                         normalize, d_off, d_d, d_mu, (double*)dr, (double*)de, (double*)dp);
+    }
+  } else {
+    PH_TRY(allow_lds(ph::k_orth_powers<float>, lds));
+    {
+      ProfScope ps_(c, "k_orth_powers");
+      hipLaunchKernelGGL(ph::k_orth_powers<float>, grid, dim3(kBlockWide), lds, c->stream, (const float*)dx, N, max_p,
+                         normalize, d_off, d_d, d_mu, (double*)dr, (double*)de, (double*)dp);
+    }
+  }
+  PH_TRY(launch_check("k_orth_powers"));
+  return st.finish();
+}
+
 }  // extern "C"

@@ -1126,6 +1126,66 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
 }
 
 // ======================================================================================
+// QOPeriods.get_best_period_orthogonal / eq_3 / auto_corr  (QOPeriods.py:1122-1232), the
+// Muresan-Parks orthogonal period powers.  One workgroup per window, window and its full
+// autocorrelation resident in LDS:
+//   r[k]   = sum_{n < N-k} x[n] x[n+k]                                   (auto_corr, :1151-1173)
+//   e3[q]  = (q/N) (r[0] + 2 sum_{l=1}^{N//q - 1} r[l q])                 (eq_3, :1122-1149)
+//   pows[q] = max(e3[q], 0) - sum_{f | q, f < q} pows[f]                  (:1210-1217)
+//           = sum_{d | q} mu(q/d) max(e3[d], 0)   (Moebius inversion of the same recursion),
+//   negatives clipped to 0 afterwards, optionally divided by q (:1218-1223).
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_orth_powers(const T* __restrict__ x, int N, int max_p, int normalize,
+                                                            const int* __restrict__ mob_off,
+                                                            const int* __restrict__ mob_d,
+                                                            const int* __restrict__ mob_mu,
+                                                            double* __restrict__ r_out, double* __restrict__ e3_out,
+                                                            double* __restrict__ pows_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* xs = cv.take<T>(N);
+  double* r = cv.take<double>(N);
+  double* m = cv.take<double>(max_p);
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  load_window(x + w * (int64_t)N, xs, N);
+  __syncthreads();
+  // autocorrelation: lags k and N-1-k are paired on one thread (N-k plus k+1 products = N+1)
+  for (int k = tid; k < (N + 1) / 2; k += blockDim.x) {
+    const int k2 = N - 1 - k;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n + k < N; ++n) a += (double)xs[n] * (double)xs[n + k];
+    if (k2 != k)
+      for (int n = 0; n + k2 < N; ++n) b += (double)xs[n] * (double)xs[n + k2];
+    r[k] = a;
+    if (k2 != k) r[k2] = b;
+  }
+  __syncthreads();
+  if (r_out)
+    for (int k = tid; k < N; k += blockDim.x) r_out[w * (int64_t)N + k] = r[k];
+  for (int q = tid; q < max_p; q += blockDim.x) {
+    double v = 0.0;
+    if (q >= 1) {
+      const int M = N / q;
+      double second = 0.0;
+      for (int l = 1; l < M; ++l) second += r[l * q];
+      v = ((double)q / (double)N) * (r[0] + 2.0 * second);
+    }
+    if (e3_out) e3_out[w * (int64_t)max_p + q] = v;
+    m[q] = fmax(v, 0.0);
+  }
+  __syncthreads();
+  for (int q = tid; q < max_p; q += blockDim.x) {
+    double v = 0.0;
+    for (int k = mob_off[q]; k < mob_off[q + 1]; ++k) v += (double)mob_mu[k] * m[mob_d[k]];
+    v = v < 0.0 ? 0.0 : v;
+    if (normalize && q >= 1) v = v / (double)q;
+    pows_out[w * (int64_t)max_p + q] = q >= 1 ? v : 0.0;
+  }
+}
+
+// ======================================================================================
 // Periods.periodic_norm over a batch (Periods.py:221-241); streams from HBM, any N.
 // ======================================================================================
 template <typename T>

@@ -326,6 +326,28 @@ class PeriodEngine:
             )
         return periods, norms, keeps, counts, weights, resid, status
 
+    def orth_powers(self, x, max_p=None, normalize=False, want_autocorr=False, want_eq3=False):
+        """Orthogonal period powers (QOPeriods.get_best_period_orthogonal(return_powers=True)).
+        -> pows (W, max_p) [, autocorr (W, N)] [, eq3 (W, max_p)]."""
+        x, code, W, N, fl, mk = self._prep(x)
+        if max_p is None:
+            max_p = N // 2
+        max_p = int(max_p)
+        pows = mk.empty((W, max_p), np.float64)
+        ac = mk.empty((W, N), np.float64) if want_autocorr else None
+        e3 = mk.empty((W, max_p), np.float64) if want_eq3 else None
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_orth_powers(self._ctx, mk.addr(x), code, W, N, max_p, 1 if normalize else 0, fl,
+                                         mk.addr(ac), mk.addr(e3), mk.addr(pows))
+            )
+        out = (pows,)
+        if want_autocorr:
+            out += (ac,)
+        if want_eq3:
+            out += (e3,)
+        return out if len(out) > 1 else pows
+
     def fold_sums(self, x, p_list, keep):
         """W = A x for natural-basis rows (QOPeriods.py:782): (W, sum(keep)) float64."""
         x, code, W, N, fl, mk = self._prep(x)

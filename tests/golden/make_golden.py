@@ -236,6 +236,22 @@ def main():
         out[f"fp_{tag}_residual"] = res
     np.savez_compressed(os.path.join(HERE, "qoperiods.npz"), **out)
 
+    # ---------------------------------------------------------------- orthogonal period powers
+    out = {}
+    for tag, sig, max_p in (
+        ("w1_n600", multi_sinusoid_window(1, 600), 200),
+        ("w2_n1000", multi_sinusoid_window(2, 1000), None),
+        ("c1", c1, 400),
+    ):
+        out[f"pows_{tag}"] = qo.get_best_period_orthogonal(sig, max_p, normalize=False, return_powers=True)
+        out[f"pows_norm_{tag}"] = qo.get_best_period_orthogonal(sig, max_p, normalize=True, return_powers=True)
+        out[f"best_{tag}"] = np.int64(qo.get_best_period_orthogonal(sig, max_p, normalize=True))
+        out[f"best_raw_{tag}"] = np.int64(qo.get_best_period_orthogonal(sig, max_p))
+    sig = multi_sinusoid_window(1, 600)
+    out["eq3_w1_n600"] = np.array([qo.eq_3(sig, q) for q in range(1, 60)])
+    out["autocorr_w1_n600"] = np.array([qo.auto_corr(sig, k) for k in range(0, 600, 7)])
+    np.savez_compressed(os.path.join(HERE, "orth_powers.npz"), **out)
+
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print(f"golden fixtures written to {HERE}: {total / 1e6:.2f} MB")
 

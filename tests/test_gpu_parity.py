@@ -317,6 +317,29 @@ def test_qoperiods_device_loop_batch_vs_oracle(eng, golden):
         assert rel_err(wts[w, :k], out["weights"]) < 1e-8 and rel_err(resid[w], res) < 1e-8
 
 
+def test_orthogonal_period_powers_match_reference_golden(eng, golden):
+    from pyperiod_amd import QOPeriods
+
+    g = golden("orth_powers")
+    qo = QOPeriods()
+    for tag, sig, max_p in (
+        ("w1_n600", multi_sinusoid_window(1, 600), 200),
+        ("w2_n1000", multi_sinusoid_window(2, 1000), None),
+        ("c1", readme_window(2000, 0), 400),
+    ):
+        assert rel_err(qo.get_best_period_orthogonal(sig, max_p, False, True), g[f"pows_{tag}"]) < TOL
+        assert rel_err(qo.get_best_period_orthogonal(sig, max_p, True, True), g[f"pows_norm_{tag}"]) < TOL
+        assert qo.get_best_period_orthogonal(sig, max_p, True) == int(g[f"best_{tag}"])
+        assert qo.get_best_period_orthogonal(sig, max_p) == int(g[f"best_raw_{tag}"])
+    sig = multi_sinusoid_window(1, 600)
+    assert rel_err([qo.eq_3(sig, q) for q in (1, 2, 7, 59)], g["eq3_w1_n600"][[0, 1, 6, 58]]) < 1e-12
+    assert rel_err([qo.auto_corr(sig, k) for k in (0, 7, 595)], g["autocorr_w1_n600"][[0, 1, 85]]) < 1e-12
+    xb = multi_sinusoid_batch(30, 5, 777)
+    pows = eng.orth_powers(xb, 300, True)
+    for w in range(5):
+        assert rel_err(pows[w], po.orth_powers(xb[w], 300, True)) < TOL
+
+
 # ------------------------------------------------------------------------------ class surface
 def test_class_surface_matches_reference_behaviour(eng):
     from pyperiod_amd import Periods

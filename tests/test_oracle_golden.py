@@ -217,3 +217,20 @@ def test_qoperiods_pieces(golden):
         assert list(out["basis_dictionary"].values()) == list(g[f"fp_{tag}_dict_vals"])
         assert rel_err(out["weights"], g[f"fp_{tag}_weights"]) < 1e-8
         assert rel_err(res, g[f"fp_{tag}_residual"]) < 1e-8
+
+
+def test_orthogonal_period_powers(golden):
+    g = golden("orth_powers")
+    for tag, sig, max_p in (
+        ("w1_n600", multi_sinusoid_window(1, 600), 200),
+        ("w2_n1000", multi_sinusoid_window(2, 1000), None),
+        ("c1", readme_window(2000, 0), 400),
+    ):
+        assert rel_err(po.orth_powers(sig, max_p), g[f"pows_{tag}"]) < TOL
+        assert rel_err(po.orth_powers(sig, max_p, True), g[f"pows_norm_{tag}"]) < TOL
+        assert po.best_period_orthogonal(sig, max_p, True) == int(g[f"best_{tag}"])
+        assert po.best_period_orthogonal(sig, max_p) == int(g[f"best_raw_{tag}"])
+    sig = multi_sinusoid_window(1, 600)
+    assert rel_err([po.eq_3(sig, q) for q in range(1, 60)], g["eq3_w1_n600"]) < 1e-12
+    assert rel_err([po.auto_corr(sig, k) for k in range(0, 600, 7)], g["autocorr_w1_n600"]) < 1e-13
+
