@@ -124,6 +124,53 @@ def test_config5_fp32_blocks(eng):
     assert rel_err(sw, po.sweep_norms(x64[0], 2, 600, gamma=True)) < 1e-4
 
 
+def test_fp32_algorithms_track_the_fp64_oracle(eng):
+    """fp32 windows through the whole algorithms (build-defined path, the reference has none):
+    period lists must agree with the fp64 oracle on the fp32-rounded input for well-separated
+    signals, powers within 1e-4."""
+    n = 2048
+    x32 = multi_sinusoid_batch(200, 4, n, dtype=np.float32)
+    x64 = x32.astype(np.float64)
+    per, pw, bs, st = eng.m_best(x32, 4)
+    assert bs.dtype == np.float32 and not st.any()
+    counts, sper, spw, sbs, sst = eng.small_to_large(x32, 0.1, cap=24)
+    ram = eng.ramanujan_norms(x32, 2, 128)
+    for w in range(4):
+        rper, rpw, rbs = po.m_best(x64[w], 4)
+        assert np.array_equal(per[w], rper), w
+        assert rel_err(pw[w], rpw) < 1e-4 and rel_err(bs[w], rbs) < 1e-4
+        lper, lpw, _ = po.small_to_large(x64[w], 0.1)
+        assert list(sper[w, : counts[w]]) == lper and rel_err(spw[w, : counts[w]], lpw) < 1e-4
+        assert rel_err(ram[w], po.ramanujan_norms_folded(x64[w], 2, 128)) < 1e-5
+
+
+def test_degenerate_windows(eng):
+    """Constant, ramp, spike and exactly periodic noise-free windows: no hangs, no faults,
+    statuses / values consistent with the oracle where the oracle is defined."""
+    from pyperiod_amd import _ffi
+
+    n = 512
+    t = np.arange(n, dtype=np.float64)
+    x = np.stack([np.full(n, 3.0), t / n, np.eye(1, n, 100)[0], np.sin(2 * np.pi * t / 8), np.zeros(n)])
+    sw = eng.sweep(x, 2, 170, _ffi.PH_SWEEP_NORM)
+    for w in range(5):
+        assert rel_err(sw[w], po.sweep_norms(x[w], 2, 170)) < 1e-10 or np.allclose(sw[w], 0)
+    per, pw, bs, st = eng.m_best(x, 3)
+    assert st[4] == _ffi.PH_ST_NO_PERIOD  # all-zero window: the reference raises
+    assert st[0] == _ffi.PH_ST_NO_PERIOD  # constant window: everything is removed by the first projection
+    assert per[0, 0] == 2  # all norms tie, the lowest period wins (Periods.py:512)
+    rper, rpw, _ = po.m_best(x[1], 3)
+    assert st[1] == 0 and np.array_equal(per[1], rper) and rel_err(pw[1], rpw) < 1e-9
+    counts, sper, spw, _, sst = eng.small_to_large(x, 0.05, want_bases=False)
+    for w in (1, 2):
+        lper, lpw, _ = po.small_to_large(x[w], 0.05)
+        assert list(sper[w, : counts[w]]) == lper
+    assert counts[4] == 0  # NaN comparisons never accept (Periods.py:281)
+    ram = eng.ramanujan_norms(x, 2, 64)
+    assert np.isfinite(ram).all()
+    assert ram[3, 8] > 0.99 * ram[3].sum()  # a pure period-8 sinusoid lives in the q = 8 subspace
+
+
 def test_batch_interface_edges(eng):
     from pyperiod_amd import Periods, _ffi
 
