@@ -63,26 +63,6 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
-  const int tid = threadIdx.x;
-  const int nw = (blockDim.x + kWave - 1) / kWave;
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if ((tid & (kWave - 1)) == 0) {
-    red[tid >> 6] = a;
-    red[kMaxWaves + (tid >> 6)] = b;
-  }
-  __syncthreads();
-  double ta = 0.0, tb = 0.0;
-  for (int i = 0; i < nw; ++i) {
-    ta += red[i];
-    tb += red[kMaxWaves + i];
-  }
-  __syncthreads();
-  a = ta;
-  b = tb;
-}
-
 // ---------------------------------------------------------------- geometry of one fold
 struct Fold {
   int p;      // period
@@ -251,11 +231,11 @@ __device__ __forceinline__ double wave_partial_small_maxabs(const T* __restrict_
 }
 
 // p < 64: G = 64/p row groups fill the wavefront (lane = g p + j reads x[lane + r G p],
-// contiguous), partial sums of a residue are combined with G shuffles.  Summation order
-// differs from the reference's; only used where the reference's own order is undefined.
+// contiguous), the G partial sums of a residue are combined with shuffles.  Every lane returns
+// S_p[lane mod p].  Summation order differs from the reference's; only used where the
+// reference's own order is undefined.
 template <typename T>
-__device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, int N, int p, const PGeom& g,
-                                                     int lane) {
+__device__ __forceinline__ double wave_fold_small(const T* __restrict__ xs, int N, int p, int lane) {
   const int G = 64 / p;
   const int L = G * p;
   const int full = N / L;  // rows of L elements that exist for every lane < L
@@ -282,6 +262,13 @@ __device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, i
   const int j = lane % p;
   double tot = 0.0;
   for (int gi = 0; gi < G; ++gi) tot += __shfl(part, j + gi * p, kWave);
+  return tot;
+}
+
+template <typename T>
+__device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, int N, int p, const PGeom& g,
+                                                     int lane) {
+  const double tot = wave_fold_small(xs, N, p, lane);
   const double w = (lane < g.nfull) ? g.w_full : g.w_short;
   return (lane < p) ? tot * tot * w : 0.0;
 }
@@ -490,7 +477,10 @@ template <typename T, int M, bool MAXABS>
 __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
                                               int lane, double (&total)[3]) {
   typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
-  constexpr int U = (M == 1) ? 2 : M;
+#ifndef PH_U1
+#define PH_U1 2  // rows per load block of single-period passes (tuning knob)
+#endif
+  constexpr int U = (M == 1) ? PH_U1 : M;
   constexpr int CM = (M == 4) ? 2 : 4;
   const int rows = geom[p].rows, cut = geom[p].nfull;  // residues < cut own `rows` samples
   int qn[3];

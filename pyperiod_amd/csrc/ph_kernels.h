@@ -779,31 +779,7 @@ __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x
         default: break;
       }
     } else {
-      // q < 64: G = 64/q row groups fill the wavefront, partials combined with G shuffles
-      const int G = 64 / q, L = G * q, full = N / L;
-      const bool on = lane < L;
-      const T* ptr = xs + (on ? lane : 0);
-      double s0 = 0.0, s1 = 0.0;
-      int r = 0;
-      for (; r + 4 <= full; r += 4) {
-        const T a = ptr[0], b = ptr[L], c = ptr[2 * L], d = ptr[3 * L];
-        s0 += (double)a;
-        s1 += (double)b;
-        s0 += (double)c;
-        s1 += (double)d;
-        ptr += 4 * L;
-      }
-      for (; r < full; ++r) {
-        s0 += (double)ptr[0];
-        ptr += L;
-      }
-      const bool tail = on && (full * L + lane < N);
-      const T tv = xs[tail ? full * L + lane : 0];
-      double part = s0 + s1 + (tail ? (double)tv : 0.0);
-      part = on ? part : 0.0;
-      const int j = lane % q;
-      double tot = 0.0;
-      for (int gi = 0; gi < G; ++gi) tot += __shfl(part, j + gi * q, kWave);
+      const double tot = wave_fold_small(xs, N, q, lane);  // row-split path, S_q[lane mod q]
       if (lane < q) sbuf[lane] = tot;
     }
     wave_sync();
