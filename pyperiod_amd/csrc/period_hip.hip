@@ -54,7 +54,7 @@ struct TableSlot {
 };
 
 enum { T_PLIST, T_ORTH_OFF, T_ORTH_Q, T_FAC_OFF, T_FAC_Q, T_AUX0, T_AUX1, T_AUX2, T_AUX3, T_COUNT };
-enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_GEN0, B_COUNT };
+enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_GEN0, B_GBUF, B_COUNT };
 
 }  // namespace
 
@@ -195,6 +195,17 @@ int check_lds(ph_ctx* c, size_t bytes, int N, const char* what) {
   if (bytes > (size_t)c->lds_limit)
     return fail(PH_E_ARG, "%s: window of N=%d needs %zu B of LDS, device limit is %d B", what, N, bytes,
                 c->lds_limit);
+  return PH_OK;
+}
+
+// Second window-sized buffer (materialised projections): in LDS when both fit, otherwise in an HBM
+// workspace of `blocks` x N elements.  `lds` comes in with the second buffer included.
+int place_second_buffer(ph_ctx* c, size_t* lds, bool needed, size_t buf_bytes, int64_t blocks, void** gbuf) {
+  *gbuf = nullptr;
+  if (!needed || *lds <= (size_t)c->lds_limit) return PH_OK;
+  *lds -= ((buf_bytes + 15) & ~size_t(15));
+  PH_TRY(ensure(c, c->buf[B_GBUF], (size_t)blocks * buf_bytes));
+  *gbuf = c->buf[B_GBUF].p;
   return PH_OK;
 }
 
@@ -474,8 +485,8 @@ int ph_max_window(ph_ctx* c, int dtype, unsigned flags, int* max_n) {
   if (!c || !max_n) return fail(PH_E_ARG, "NULL argument");
   const size_t sz = elem_size(dtype);
   const size_t overhead = 8192;  // reduction scratch, bookkeeping arrays
-  const size_t bufs = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) ? 2 : 1;
-  *max_n = (int)(((size_t)c->lds_limit - overhead) / (sz * bufs));
+  (void)flags;  // a second (projection) buffer moves to an HBM workspace when LDS cannot hold two
+  *max_n = (int)(((size_t)c->lds_limit - overhead) / sz);
   return PH_OK;
 }
 
@@ -494,6 +505,9 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
   const size_t sz = elem_size(dtype);
   const int scratch_len = (flags & PH_FLAG_ORTH) ? N : std::min(pmax, N);
   size_t lds = carve_bytes(N, sz) + carve_bytes(scratch_len, sz);
+  const int chunks = pick_chunks(c, W, n_p, 1);
+  void* gbuf;
+  PH_TRY(place_second_buffer(c, &lds, true, (size_t)scratch_len * sz, W * chunks, &gbuf));
   PH_TRY(check_lds(c, lds, N, "ph_project_batch"));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, pmax, &tb));
@@ -504,7 +518,6 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
   void* dout;
   PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
   PH_TRY(st.out(B_OUT0, out, (size_t)W * n_p * N * sz, &dout));
-  const int chunks = pick_chunks(c, W, n_p, 1);
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH | PH_FLAG_SINGLE);
   if (flags & PH_FLAG_SINGLE) PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * n_p * N * sz, c->stream));
   const dim3 grid((unsigned)(W * chunks));
@@ -513,14 +526,14 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
     {
       ProfScope ps_(c, "k_project_batch");
       hipLaunchKernelGGL(ph::k_project_batch<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                         d_plist, n_p, chunks, kflags, tb, scratch_len, (double*)dout);
+                         d_plist, n_p, chunks, kflags, tb, scratch_len, (double*)gbuf, (double*)dout);
     }
   } else {
     PH_TRY(allow_lds(ph::k_project_batch<float>, lds));
     {
       ProfScope ps_(c, "k_project_batch");
       hipLaunchKernelGGL(ph::k_project_batch<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                         d_plist, n_p, chunks, kflags, tb, scratch_len, (float*)dout);
+                         d_plist, n_p, chunks, kflags, tb, scratch_len, (float*)gbuf, (float*)dout);
     }
   }
   PH_TRY(launch_check("k_project_batch"));
@@ -538,6 +551,10 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   const size_t sz = elem_size(dtype);
   const bool general = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) && mode != PH_SWEEP_MAXABS;
   size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8);
+  const int P = p_hi - p_lo + 1;
+  const int chunks = pick_chunks(c, W, P, 8 * (c->sweep_block / 64));
+  void* gbuf;
+  PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W * chunks, &gbuf));
   PH_TRY(check_lds(c, lds, N, "ph_sweep"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, p_hi, &geom));
@@ -546,13 +563,11 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   PH_TRY(prepare_plan(c, p_lo, p_hi, &plan, &n_pass));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, general ? flags : 0u, orth_off, orth_q, table_max_p, p_hi, &tb));
-  const int P = p_hi - p_lo + 1;
   Stage st(c, flags);
   const void* dx;
   void* dout;
   PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
   PH_TRY(st.out(B_OUT0, out, (size_t)W * P * sizeof(double), &dout));
-  const int chunks = pick_chunks(c, W, P, 8 * (c->sweep_block / 64));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)(W * chunks));
   if (dtype == PH_F64) {
@@ -560,14 +575,14 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
     {
       ProfScope ps_(c, "k_sweep");
       hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, p_lo,
-                         p_hi, mode, chunks, kflags, tb, geom, plan, n_pass, (double*)dout);
+                         p_hi, mode, chunks, kflags, tb, geom, plan, n_pass, (double*)gbuf, (double*)dout);
     }
   } else {
     PH_TRY(allow_lds(ph::k_sweep<float>, lds));
     {
       ProfScope ps_(c, "k_sweep");
       hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
-                         mode, chunks, kflags, tb, geom, plan, n_pass, (double*)dout);
+                         mode, chunks, kflags, tb, geom, plan, n_pass, (float*)gbuf, (double*)dout);
     }
   }
   PH_TRY(launch_check("k_sweep"));
@@ -596,6 +611,9 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   for (int q = 0; q <= max_length; ++q) max_fac = std::max(max_fac, fac_off ? fac_off[q + 1] - fac_off[q] : 0);
   size_t lds2 = carve_bytes(N + kPad, sz) + carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) +
                 carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8);
+  void *gbuf1, *gbuf2;
+  PH_TRY(place_second_buffer(c, &lds1, general, (size_t)N * sz, W, &gbuf1));
+  PH_TRY(place_second_buffer(c, &lds2, true, (size_t)N * sz, W, &gbuf2));
   PH_TRY(check_lds(c, std::max(lds1, lds2), N, "ph_m_best"));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, max_length, &tb));
@@ -626,14 +644,14 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     {
       ProfScope ps_(c, "k_mbest_step1");
       hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(c->sweep_block), lds1, c->stream, (const double*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, max_iters, (uint32_t*)dper, (double*)dpow,
+                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, (double*)gbuf1, max_iters, (uint32_t*)dper, (double*)dpow,
                          (double*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     }
     PH_TRY(launch_check("k_mbest_step1"));
     {
       ProfScope ps_(c, "k_mbest_step2");
       hipLaunchKernelGGL(ph::k_mbest_step2<double>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                         kflags, tb, geom, max_fac, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
+                         kflags, tb, geom, max_fac, (double*)gbuf2, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
     }
   } else {
     PH_TRY(allow_lds(ph::k_mbest_step1<float>, lds1));
@@ -641,14 +659,14 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     {
       ProfScope ps_(c, "k_mbest_step1");
       hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(c->sweep_block), lds1, c->stream, (const float*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, max_iters, (uint32_t*)dper, (double*)dpow,
+                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, (float*)gbuf1, max_iters, (uint32_t*)dper, (double*)dpow,
                          (float*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     }
     PH_TRY(launch_check("k_mbest_step1"));
     {
       ProfScope ps_(c, "k_mbest_step2");
       hipLaunchKernelGGL(ph::k_mbest_step2<float>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                         kflags, tb, geom, max_fac, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
+                         kflags, tb, geom, max_fac, (float*)gbuf2, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
     }
   }
   PH_TRY(launch_check("k_mbest_step2"));
@@ -668,6 +686,8 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
                carve_bytes(ph::kS2LBatch, 8) + carve_bytes(4, 4);
+  void* gbuf;
+  PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W, &gbuf));
   PH_TRY(check_lds(c, lds, N, "ph_small_to_large"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, std::max(n_periods, 2), &geom));
@@ -691,7 +711,7 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
     {
       ProfScope ps_(c, "k_small_to_large");
       hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N,
-                         thresh, n_periods, kflags, tb, geom, cap, (int*)dcnt, (int*)dper, (double*)dpow,
+                         thresh, n_periods, kflags, tb, geom, (double*)gbuf, cap, (int*)dcnt, (int*)dper, (double*)dpow,
                          (double*)dbases, (int*)dstat);
     }
   } else {
@@ -699,7 +719,7 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
     {
       ProfScope ps_(c, "k_small_to_large");
       hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N,
-                         thresh, n_periods, kflags, tb, geom, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
+                         thresh, n_periods, kflags, tb, geom, (float*)gbuf, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
                          (int*)dstat);
     }
   }
@@ -726,6 +746,8 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
                carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+  void* gbuf;
+  PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W, &gbuf));
   PH_TRY(check_lds(c, lds, N, "ph_best_correlation"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, std::max(max_length, 2), &geom));
@@ -746,7 +768,7 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
     {
       ProfScope ps_(c, "k_best_correlation");
       hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N,
-                         num, max_length, ratio, kflags, tb, geom, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
+                         num, max_length, ratio, kflags, tb, geom, (double*)gbuf, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
                          (int*)dstat);
     }
   } else {
@@ -754,7 +776,7 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
     {
       ProfScope ps_(c, "k_best_correlation");
       hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N,
-                         num, max_length, ratio, kflags, tb, geom, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
+                         num, max_length, ratio, kflags, tb, geom, (float*)gbuf, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
                          (int*)dstat);
     }
   }

@@ -42,12 +42,13 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ x, int N,
                                                           const int* __restrict__ p_list, int n_p, int chunks,
                                                           unsigned flags, Tables tb, int scratch_len,
-                                                          T* __restrict__ out) {
+                                                          T* __restrict__ gbuf, T* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* xs = cv.take<T>(N);
-  // orth: the whole projection is materialised here; otherwise only one period of means
-  T* buf = cv.take<T>(scratch_len);
+  // orth: the whole projection is materialised here; otherwise only one period of means.
+  // gbuf != nullptr: the window is too long for two LDS buffers, the second one lives in HBM.
+  T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * scratch_len : cv.take<T>(scratch_len);
 
   const int64_t w = blockIdx.x / chunks;
   const int c = blockIdx.x % chunks;
@@ -116,12 +117,12 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
                                                       int chunks, unsigned flags, Tables tb,
                                                       const PGeom* __restrict__ geom,
                                                       const PassPlan* __restrict__ plan, int n_pass,
-                                                      double* __restrict__ out) {
+                                                      T* __restrict__ gbuf, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* xs = cv.take<T>(N + kPad);
   const bool general = (flags & (kTrunc | kOrth)) && mode != 2;
-  T* buf = general ? cv.take<T>(N) : nullptr;
+  T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
 
   const int64_t w = blockIdx.x / chunks;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
                                                         const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
+                                                        T* __restrict__ gbuf,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, T* __restrict__ bases_out,
                                                         double* __restrict__ dnorm_out,
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   Carve cv(smem);
   T* work = cv.take<T>(N + kPad);
   const bool general = flags & (kTrunc | kOrth);
-  T* buf = general ? cv.take<T>(N) : nullptr;
+  T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
   double* wbest = cv.take<double>(kMaxWaves);
   int* wbestp = cv.take<int>(kMaxWaves);
@@ -351,14 +353,14 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
                                                         Tables tb, const PGeom* __restrict__ geom, int max_fac,
-                                                        uint32_t* __restrict__ periods_io,
+                                                        T* __restrict__ gbuf, uint32_t* __restrict__ periods_io,
                                                         double* __restrict__ norms_io, T* __restrict__ bases_io,
                                                         const double* __restrict__ dnorm,
                                                         const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* rowbuf = cv.take<T>(N + kPad);
-  T* buf = cv.take<T>(N);
+  T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
   double* norms = cv.take<double>(num);
   uint32_t* periods = cv.take<uint32_t>(num);
@@ -479,15 +481,16 @@ constexpr int kS2LBatch = 64;  // periods screened speculatively per round (8 wa
 template <typename T>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
                                                            int n_periods, unsigned flags, Tables tb,
-                                                           const PGeom* __restrict__ geom, int cap,
-                                                           int* __restrict__ counts, int* __restrict__ periods_out,
+                                                           const PGeom* __restrict__ geom, T* __restrict__ gbuf,
+                                                           int cap, int* __restrict__ counts,
+                                                           int* __restrict__ periods_out,
                                                            double* __restrict__ powers_out,
                                                            T* __restrict__ bases_out, int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* work = cv.take<T>(N + kPad);
   const bool general = flags & (kTrunc | kOrth);
-  T* buf = general ? cv.take<T>(N) : nullptr;
+  T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
   double* psq = cv.take<double>(kS2LBatch);
   int* cand_slot = cv.take<int>(4);
@@ -606,6 +609,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_best_correlation(const T* __restrict__ x, int N, int num,
                                                              int max_length, double ratio, unsigned flags,
                                                              Tables tb, const PGeom* __restrict__ geom,
+                                                             T* __restrict__ gbuf,
                                                              uint32_t* __restrict__ periods_out,
                                                              double* __restrict__ norms_out,
                                                              T* __restrict__ bases_out,
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   Carve cv(smem);
   T* work = cv.take<T>(N + kPad);
   const bool general = flags & (kTrunc | kOrth);
-  T* buf = general ? cv.take<T>(N) : nullptr;
+  T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
   double* wbest = cv.take<double>(kMaxWaves);
   int* wbestp = cv.take<int>(kMaxWaves);

@@ -171,6 +171,31 @@ def test_degenerate_windows(eng):
     assert ram[3, 8] > 0.99 * ram[3].sum()  # a pure period-8 sinusoid lives in the q = 8 subspace
 
 
+def test_long_windows_spill_second_buffer_to_hbm(eng):
+    """N = 16384 fp64: two window-sized LDS buffers do not fit (256 KiB), so the projection
+    buffer of the flagged paths and of m_best step 2 lives in an HBM workspace."""
+    from pyperiod_amd import _ffi
+
+    n = 16384
+    x = multi_sinusoid_batch(300, 2, n)
+    for trunc, orth in ((False, True), (True, True)):
+        out = eng.project_batch(x, [37, 1260, 4096], trunc, orth)
+        for w in range(2):
+            for k, p in enumerate([37, 1260, 4096]):
+                assert np.array_equal(out[w, k], po.project(x[w], p, trunc, orth)), (trunc, orth, p)
+    sw = eng.sweep(x[:1], 2, 90, _ffi.PH_SWEEP_NORM, True, True)[0]
+    assert rel_err(sw, po.sweep_norms(x[0], 2, 90, trunc=True, orth=True)) < TOL
+    per, pw, bs, st = eng.m_best(x, 3, 400)
+    for w in range(2):
+        rper, rpw, rbs = po.m_best(x[w], 3, 400)
+        assert st[w] == 0 and np.array_equal(per[w], rper)
+        assert rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL
+    counts, sper, spw, sbs, _ = eng.small_to_large(x[:1], 0.05, 300, True, False)
+    lper, lpw, lbs = po.small_to_large(x[0], 0.05, 300, True, False)
+    assert list(sper[0, : counts[0]]) == lper and rel_err(spw[0, : counts[0]], lpw) < TOL
+    assert eng.max_window(np.float64, True, True) >= n
+
+
 def test_batch_interface_edges(eng):
     from pyperiod_amd import Periods, _ffi
 
