@@ -94,7 +94,10 @@ int ph_profile_read(ph_ctx* ctx, float* ms, int cap, int* count);
 const char* ph_profile_name(ph_ctx* ctx, int i);
 /* Multiprocessor count and per-workgroup LDS limit of the context's device. */
 int ph_device_info(ph_ctx* ctx, int* num_cu, int* lds_bytes);
-/* Largest N the window-resident kernels accept for `dtype` with `flags`. */
+/* Largest N for which a window of `dtype` stays LDS-resident (the fast path).  Longer windows are
+ * accepted by project/sweep/m_best/small_to_large/best_correlation/ramanujan_norms -- the window
+ * then lives in an HBM workspace -- and rejected (PH_E_ARG) by qo_find_periods, fold_sums and
+ * orth_powers.  `flags` is ignored. */
 int ph_max_window(ph_ctx* ctx, int dtype, unsigned flags, int* max_n);
 
 /* ---- Periods.periodic_norm over a batch (Periods.py:221-241) ---------------------------

@@ -54,7 +54,7 @@ struct TableSlot {
 };
 
 enum { T_PLIST, T_ORTH_OFF, T_ORTH_Q, T_FAC_OFF, T_FAC_Q, T_AUX0, T_AUX1, T_AUX2, T_AUX3, T_COUNT };
-enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_GEN0, B_GBUF, B_COUNT };
+enum { B_IN, B_OUT0, B_OUT1, B_OUT2, B_OUT3, B_OUT4, B_WS0, B_WS1, B_GEN0, B_GBUF, B_GWIN, B_COUNT };
 
 }  // namespace
 
@@ -207,6 +207,25 @@ int place_second_buffer(ph_ctx* c, size_t* lds, bool needed, size_t buf_bytes, i
   PH_TRY(ensure(c, c->buf[B_GBUF], (size_t)blocks * buf_bytes));
   *gbuf = c->buf[B_GBUF].p;
   return PH_OK;
+}
+
+// Window buffer: LDS when it fits (after the second buffer has been placed), otherwise an HBM
+// workspace of `blocks` slices that the kernels' <T, false> instantiations fold through L2.
+// `lds` comes in with the window buffer included.
+int place_window(ph_ctx* c, size_t* lds, size_t win_len, size_t sz, int64_t blocks, void** gwin) {
+  *gwin = nullptr;
+  if (*lds <= (size_t)c->lds_limit) return PH_OK;
+  *lds -= ph::carve_bytes(win_len, sz);
+  PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)blocks * ph::win_stride(win_len) * sz));
+  *gwin = c->buf[B_GWIN].p;
+  return PH_OK;
+}
+
+// f(T{}, std::bool_constant<window in LDS>{}) for the runtime element type / window placement.
+template <typename F>
+int dispatch(int dtype, bool lds_window, F&& f) {
+  if (dtype == PH_F64) return lds_window ? f(double{}, std::true_type{}) : f(double{}, std::false_type{});
+  return lds_window ? f(float{}, std::true_type{}) : f(float{}, std::false_type{});
 }
 
 template <typename K>
@@ -508,6 +527,8 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
   const int chunks = pick_chunks(c, W, n_p, 1);
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, true, (size_t)scratch_len * sz, W * chunks, &gbuf));
+  void* gwin;
+  PH_TRY(place_window(c, &lds, N, sz, W * chunks, &gwin));
   PH_TRY(check_lds(c, lds, N, "ph_project_batch"));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, pmax, &tb));
@@ -521,21 +542,15 @@ int ph_project_batch(ph_ctx* c, const void* x, int dtype, int64_t W, int N, cons
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH | PH_FLAG_SINGLE);
   if (flags & PH_FLAG_SINGLE) PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * n_p * N * sz, c->stream));
   const dim3 grid((unsigned)(W * chunks));
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_project_batch<double>, lds));
-    {
-      ProfScope ps_(c, "k_project_batch");
-      hipLaunchKernelGGL(ph::k_project_batch<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N,
-                         d_plist, n_p, chunks, kflags, tb, scratch_len, (double*)gbuf, (double*)dout);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_project_batch<float>, lds));
-    {
-      ProfScope ps_(c, "k_project_batch");
-      hipLaunchKernelGGL(ph::k_project_batch<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N,
-                         d_plist, n_p, chunks, kflags, tb, scratch_len, (float*)gbuf, (float*)dout);
-    }
-  }
+  PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_project_batch<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_project_batch");
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, c->stream, (const T*)dx, N, d_plist, n_p, chunks, kflags, tb,
+                       scratch_len, (T*)gbuf, (T*)gwin, (T*)dout);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_project_batch"));
   return st.finish();
 }
@@ -555,6 +570,8 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   const int chunks = pick_chunks(c, W, P, 8 * (c->sweep_block / 64));
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W * chunks, &gbuf));
+  void* gwin;
+  PH_TRY(place_window(c, &lds, N + kPad, sz, W * chunks, &gwin));
   PH_TRY(check_lds(c, lds, N, "ph_sweep"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, p_hi, &geom));
@@ -570,21 +587,15 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   PH_TRY(st.out(B_OUT0, out, (size_t)W * P * sizeof(double), &dout));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)(W * chunks));
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_sweep<double>, lds));
-    {
-      ProfScope ps_(c, "k_sweep");
-      hipLaunchKernelGGL(ph::k_sweep<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, p_lo,
-                         p_hi, mode, chunks, kflags, tb, geom, plan, n_pass, (double*)gbuf, (double*)dout);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_sweep<float>, lds));
-    {
-      ProfScope ps_(c, "k_sweep");
-      hipLaunchKernelGGL(ph::k_sweep<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, p_lo, p_hi,
-                         mode, chunks, kflags, tb, geom, plan, n_pass, (float*)gbuf, (double*)dout);
-    }
-  }
+  PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_sweep<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_sweep");
+    hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds, c->stream, (const T*)dx, N, p_lo, p_hi, mode, chunks,
+                       kflags, tb, geom, plan, n_pass, (T*)gbuf, (T*)gwin, (double*)dout);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_sweep"));
   return st.finish();
 }
@@ -614,6 +625,9 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   void *gbuf1, *gbuf2;
   PH_TRY(place_second_buffer(c, &lds1, general, (size_t)N * sz, W, &gbuf1));
   PH_TRY(place_second_buffer(c, &lds2, true, (size_t)N * sz, W, &gbuf2));
+  void *gwin1, *gwin2;  // the two kernels run back to back on one stream and may share the workspace
+  PH_TRY(place_window(c, &lds1, N + kPad, sz, W, &gwin1));
+  PH_TRY(place_window(c, &lds2, N + kPad, sz, W, &gwin2));
   PH_TRY(check_lds(c, std::max(lds1, lds2), N, "ph_m_best"));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, max_length, &tb));
@@ -638,37 +652,27 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const int max_iters = 12 * (P + num) + 64;
   const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_mbest_step1<double>, lds1));
-    PH_TRY(allow_lds(ph::k_mbest_step2<double>, lds2));
-    {
-      ProfScope ps_(c, "k_mbest_step1");
-      hipLaunchKernelGGL(ph::k_mbest_step1<double>, grid, dim3(c->sweep_block), lds1, c->stream, (const double*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, (double*)gbuf1, max_iters, (uint32_t*)dper, (double*)dpow,
-                         (double*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
-    }
-    PH_TRY(launch_check("k_mbest_step1"));
-    {
-      ProfScope ps_(c, "k_mbest_step2");
-      hipLaunchKernelGGL(ph::k_mbest_step2<double>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                         kflags, tb, geom, max_fac, (double*)gbuf2, (uint32_t*)dper, (double*)dpow, (double*)dbases, dnorm, (const int*)dstat);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_mbest_step1<float>, lds1));
-    PH_TRY(allow_lds(ph::k_mbest_step2<float>, lds2));
-    {
-      ProfScope ps_(c, "k_mbest_step1");
-      hipLaunchKernelGGL(ph::k_mbest_step1<float>, grid, dim3(c->sweep_block), lds1, c->stream, (const float*)dx, N, num,
-                         min_length, max_length, gamma, kflags, tb, geom, plan, n_pass, (float*)gbuf1, max_iters, (uint32_t*)dper, (double*)dpow,
-                         (float*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
-    }
-    PH_TRY(launch_check("k_mbest_step1"));
-    {
-      ProfScope ps_(c, "k_mbest_step2");
-      hipLaunchKernelGGL(ph::k_mbest_step2<float>, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length,
-                         kflags, tb, geom, max_fac, (float*)gbuf2, (uint32_t*)dper, (double*)dpow, (float*)dbases, dnorm, (const int*)dstat);
-    }
-  }
+  PH_TRY(dispatch(dtype, !gwin1, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_mbest_step1<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds1));
+    ProfScope ps_(c, "k_mbest_step1");
+    hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds1, c->stream, (const T*)dx, N, num, min_length,
+                       max_length, gamma, kflags, tb, geom, plan, n_pass, (T*)gbuf1, (T*)gwin1, max_iters,
+                       (uint32_t*)dper, (double*)dpow, (T*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
+    return (int)PH_OK;
+  }));
+  PH_TRY(launch_check("k_mbest_step1"));
+  PH_TRY(dispatch(dtype, !gwin2, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_mbest_step2<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds2));
+    ProfScope ps_(c, "k_mbest_step2");
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length, kflags, tb, geom,
+                       max_fac, (T*)gbuf2, (T*)gwin2, (uint32_t*)dper, (double*)dpow, (T*)dbases, dnorm,
+                       (const int*)dstat);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_mbest_step2"));
   return st.finish();
 }
@@ -688,6 +692,8 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
                carve_bytes(ph::kS2LBatch, 8) + carve_bytes(4, 4);
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W, &gbuf));
+  void* gwin;
+  PH_TRY(place_window(c, &lds, N + kPad, sz, W, &gwin));
   PH_TRY(check_lds(c, lds, N, "ph_small_to_large"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, std::max(n_periods, 2), &geom));
@@ -706,23 +712,16 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   PH_HIP(hipMemsetAsync(dpow, 0, (size_t)W * cap * sizeof(double), c->stream));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_small_to_large<double>, lds));
-    {
-      ProfScope ps_(c, "k_small_to_large");
-      hipLaunchKernelGGL(ph::k_small_to_large<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N,
-                         thresh, n_periods, kflags, tb, geom, (double*)gbuf, cap, (int*)dcnt, (int*)dper, (double*)dpow,
-                         (double*)dbases, (int*)dstat);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_small_to_large<float>, lds));
-    {
-      ProfScope ps_(c, "k_small_to_large");
-      hipLaunchKernelGGL(ph::k_small_to_large<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N,
-                         thresh, n_periods, kflags, tb, geom, (float*)gbuf, cap, (int*)dcnt, (int*)dper, (double*)dpow, (float*)dbases,
-                         (int*)dstat);
-    }
-  }
+  PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_small_to_large<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_small_to_large");
+    hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds, c->stream, (const T*)dx, N, thresh, n_periods, kflags,
+                       tb, geom, (T*)gbuf, (T*)gwin, cap, (int*)dcnt, (int*)dper, (double*)dpow, (T*)dbases,
+                       (int*)dstat);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_small_to_large"));
   PH_TRY(st.finish());
   if (!(flags & PH_FLAG_DEVICE)) {
@@ -748,6 +747,8 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
                carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W, &gbuf));
+  void* gwin;
+  PH_TRY(place_window(c, &lds, N + kPad, sz, W, &gwin));
   PH_TRY(check_lds(c, lds, N, "ph_best_correlation"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, std::max(max_length, 2), &geom));
@@ -763,23 +764,15 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_best_correlation<double>, lds));
-    {
-      ProfScope ps_(c, "k_best_correlation");
-      hipLaunchKernelGGL(ph::k_best_correlation<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N,
-                         num, max_length, ratio, kflags, tb, geom, (double*)gbuf, (uint32_t*)dper, (double*)dnrm, (double*)dbases,
-                         (int*)dstat);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_best_correlation<float>, lds));
-    {
-      ProfScope ps_(c, "k_best_correlation");
-      hipLaunchKernelGGL(ph::k_best_correlation<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N,
-                         num, max_length, ratio, kflags, tb, geom, (float*)gbuf, (uint32_t*)dper, (double*)dnrm, (float*)dbases,
-                         (int*)dstat);
-    }
-  }
+  PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_best_correlation<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_best_correlation");
+    hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds, c->stream, (const T*)dx, N, num, max_length, ratio,
+                       kflags, tb, geom, (T*)gbuf, (T*)gwin, (uint32_t*)dper, (double*)dnrm, (T*)dbases, (int*)dstat);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_best_correlation"));
   return st.finish();
 }
@@ -794,6 +787,8 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   const size_t sz = elem_size(dtype);
   const int nw = ph::kRamBlock / 64;
   size_t lds = carve_bytes(N + kPad, sz) + carve_bytes((size_t)nw * q_hi, 8);
+  void* gwin;
+  PH_TRY(place_window(c, &lds, N + kPad, sz, W, &gwin));
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, q_hi, &geom));
@@ -830,21 +825,15 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * (q_hi + 1) * sizeof(double), c->stream));
   const dim3 grid((unsigned)W);
   if (q_lo <= q_hi) {
-    if (dtype == PH_F64) {
-      PH_TRY(allow_lds(ph::k_ramanujan<double>, lds));
-      {
-        ProfScope ps_(c, "k_ramanujan");
-        hipLaunchKernelGGL(ph::k_ramanujan<double>, grid, dim3(ph::kRamBlock), lds, c->stream, (const double*)dx, N,
-                           q_lo, q_hi, geom, d_off, d_d, d_phi, (double*)dout);
-      }
-    } else {
-      PH_TRY(allow_lds(ph::k_ramanujan<float>, lds));
-      {
-        ProfScope ps_(c, "k_ramanujan");
-        hipLaunchKernelGGL(ph::k_ramanujan<float>, grid, dim3(ph::kRamBlock), lds, c->stream, (const float*)dx, N,
-                           q_lo, q_hi, geom, d_off, d_d, d_phi, (double*)dout);
-      }
-    }
+    PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
+      using T = decltype(t);
+      auto kernel = ph::k_ramanujan<T, decltype(lw)::value>;
+      PH_TRY(allow_lds(kernel, lds));
+      ProfScope ps_(c, "k_ramanujan");
+      hipLaunchKernelGGL(kernel, grid, dim3(ph::kRamBlock), lds, c->stream, (const T*)dx, N, q_lo, q_hi, geom, d_off,
+                         d_d, d_phi, (T*)gwin, (double*)dout);
+      return (int)PH_OK;
+    }));
     PH_TRY(launch_check("k_ramanujan"));
   }
   return st.finish();

@@ -182,6 +182,22 @@ struct PGeom {
   double w_short;  // 1 / (R-1)   (0 when R == 1)
 };
 
+// Where a window lives: in LDS (the normal case; volatile LDS-address-space reads, see
+// fold_rows) or -- for windows longer than the LDS -- in a per-workgroup HBM workspace that the
+// same code reads through ordinary global loads (served by L2).
+template <typename T, bool LDS>
+struct Win;
+template <typename T>
+struct Win<T, true> {
+  typedef const volatile __attribute__((address_space(3))) T* ptr;
+  static __device__ __forceinline__ ptr cast(const T* p) { return (ptr)p; }
+};
+template <typename T>
+struct Win<T, false> {
+  typedef const T* ptr;
+  static __device__ __forceinline__ ptr cast(const T* p) { return p; }
+};
+
 constexpr int kPad = 256;  // LDS windows are followed by kPad zeroed elements: a 4-chunk group reads up to
                            // 255 elements past the last row of the window (see seg_group)
 
@@ -192,9 +208,8 @@ constexpr int kPad = 256;  // LDS windows are followed by kPad zeroed elements: 
 // row share one address register (immediate offsets 512 c) and hipcc cannot fuse chunk pairs
 // into ds_read2st64_b64, which runs at half the LDS rate of ds_read_b64.  Row order per
 // residue is preserved (bit-identical column sums).
-template <typename T, int C, int U>
-__device__ __forceinline__ void fold_rows(const volatile __attribute__((address_space(3))) T* ptr, int p,
-                                          int nrows, double (&s)[C]) {
+template <typename T, int C, int U, bool LDS = true>
+__device__ __forceinline__ void fold_rows(typename Win<T, LDS>::ptr ptr, int p, int nrows, double (&s)[C]) {
   int r = 0;
   for (; r + U <= nrows; r += U) {
     T v[U][C];
@@ -273,15 +288,15 @@ __device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, i
   return (lane < p) ? tot * tot * w : 0.0;
 }
 
-template <typename T, int M, bool MAXABS>
+template <typename T, int M, bool MAXABS, bool LDS>
 __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
                                               int lane, double (&part)[3]);
 
-template <typename T, bool MAXABS>
+template <typename T, bool MAXABS, bool LDS = true>
 __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, int p, const PGeom& g, int lane) {
   if (p >= 64) {
     double part[3];
-    wave_pass_seg<T, 1, MAXABS>(xs, p, &g - p, lane, part);  // &g == geom + p
+    wave_pass_seg<T, 1, MAXABS, LDS>(xs, p, &g - p, lane, part);  // &g == geom + p
     return part[0];
   }
   return MAXABS ? wave_partial_small_maxabs(xs, p, g, lane) : wave_partial_small(xs, N, p, g, lane);
@@ -350,7 +365,7 @@ __device__ __forceinline__ int butterfly8_slot(int lane) {
 // Visit ||P_p x||^2 (or max_s |S_p[s]| when MAXABS) for p = p_first, p_first + stride, ...
 // <= p_hi.  consume(value, p) runs in the 8 lanes that own period p.  p_first and stride
 // must be wave-uniform.
-template <typename T, bool MAXABS, typename F>
+template <typename T, bool MAXABS, bool LDS, typename F>
 __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
                                            int p_first, int p_hi, int stride, int lane, F&& consume) {
   for (int pb = p_first; pb <= p_hi; pb += 8 * stride) {
@@ -358,7 +373,7 @@ __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, cons
     for (int k = 0; k < 8; ++k) {
       const int p = pb + k * stride;
       double a = 0.0;
-      if (p <= p_hi) a = wave_partial<T, MAXABS>(xs, N, p, geom[p], lane);
+      if (p <= p_hi) a = wave_partial<T, MAXABS, LDS>(xs, N, p, geom[p], lane);
       if ((k & 1) == 0) {
         l1 = a;
         continue;
@@ -405,9 +420,9 @@ struct PassPlan {
 // blocks of U (U = M for M >= 2; row class u = r mod M); a[u][c] keeps row-order sums.
 // acc layout: [0] period p, [1..2] period 2p (u = 0, 1), [3..6] period 4p (u = 0..3);
 // wgt holds the matching scalar weights of this segment.
-template <typename T, int M, int U, int C, bool MAXABS, bool MASK>
-__device__ __forceinline__ void seg_group(const volatile __attribute__((address_space(3))) T* ptr, int p, int nrows,
-                                          int nvalid, int lane, const double (&wgt)[7], double (&part)[3]) {
+template <typename T, int M, int U, int C, bool MAXABS, bool MASK, bool LDS>
+__device__ __forceinline__ void seg_group(typename Win<T, LDS>::ptr ptr, int p, int nrows, int nvalid, int lane,
+                                          const double (&wgt)[7], double (&part)[3]) {
   static_assert(U % M == 0, "a row block must cover whole class cycles");
   double a[M][C];
 #pragma unroll
@@ -473,10 +488,10 @@ __device__ __forceinline__ void seg_group(const volatile __attribute__((address_
 
 // Per-lane partials of ||P_q x||^2 for q = p (M >= 1), 2p (M >= 2), 4p (M == 4) -- or of
 // max_s |S_p[s]| (MAXABS, M == 1, row-order sums) -- for a base period p >= 64.
-template <typename T, int M, bool MAXABS>
+template <typename T, int M, bool MAXABS, bool LDS>
 __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
                                               int lane, double (&total)[3]) {
-  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
+  typedef typename Win<T, LDS>::ptr lds_ptr;
 #ifndef PH_U1
 #define PH_U1 2  // rows per load block of single-period passes (tuning knob)
 #endif
@@ -505,26 +520,26 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
     for (int u = 0; u < 2; ++u) wgt[1 + u] = (start + u * p < qn[1]) ? qf[1] : qs[1];
 #pragma unroll
     for (int u = 0; u < 4; ++u) wgt[3 + u] = (start + u * p < qn[2]) ? qf[2] : qs[2];
-    const lds_ptr base = (lds_ptr)xs + start + lane;
+    const lds_ptr base = Win<T, LDS>::cast(xs) + start + lane;
     const int nchunks = (len + 63) >> 6;
     int c0 = 0;
     const int whole = len >> 6;  // chunks whose 64 residues all belong to the segment
     double sacc[3] = {0.0, 0.0, 0.0};
     double(&part)[3] = (M <= 2) ? sacc : total;
     for (; c0 + CM <= whole; c0 += CM)
-      seg_group<T, M, U, CM, MAXABS, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
+      seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
     if (CM == 4) {
       switch (nchunks - c0) {
-        case 4: seg_group<T, M, U, 4, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 3: seg_group<T, M, U, 3, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 2: seg_group<T, M, U, 2, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: seg_group<T, M, U, 1, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 4: seg_group<T, M, U, 4, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 3: seg_group<T, M, U, 3, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 2: seg_group<T, M, U, 2, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: seg_group<T, M, U, 1, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         default: break;
       }
     } else {
       switch (nchunks - c0) {
-        case 2: seg_group<T, M, U, 2, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: seg_group<T, M, U, 1, MAXABS, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 2: seg_group<T, M, U, 2, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: seg_group<T, M, U, 1, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         default: break;
       }
     }
@@ -578,7 +593,7 @@ struct Butterfly8 {
 // Norm sweep driven by a pass plan: visits ||P_q x||^2 of every period the passes
 // plan[i_first], plan[i_first + stride], ... (< i_end) produce.  Periods arrive out of order;
 // consume(value, q) runs in the 8 lanes that own q.
-template <typename T, typename F>
+template <typename T, bool LDS, typename F>
 __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end,
                                                 int stride, int lane, F&& consume) {
@@ -587,15 +602,15 @@ __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N,
   for (int i = i_first; i < i_end; i += stride) {
     const int p = plan[i].p, m = plan[i].m;
     if (m <= 1) {
-      bf.push(wave_partial<T, false>(xs, N, p, geom[p], lane), p, lane, consume);
+      bf.push(wave_partial<T, false, LDS>(xs, N, p, geom[p], lane), p, lane, consume);
     } else if (m == 2) {
       double part[3];
-      wave_pass_seg<T, 2, false>(xs, p, geom, lane, part);
+      wave_pass_seg<T, 2, false, LDS>(xs, p, geom, lane, part);
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
     } else {
       double part[3];
-      wave_pass_seg<T, 4, false>(xs, p, geom, lane, part);
+      wave_pass_seg<T, 4, false, LDS>(xs, p, geom, lane, part);
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
       bf.push(part[2], 4 * p, lane, consume);

@@ -24,6 +24,19 @@ struct Carve {
 
 __host__ __device__ inline size_t carve_bytes(size_t n, size_t elem) { return (n * elem + 15) & ~size_t(15); }
 
+// The window buffer of workgroup blockIdx.x: LDS normally; for windows longer than the LDS
+// (LW == false) a slice of the HBM workspace `gwin` (stride win_stride(len) elements).
+__host__ __device__ inline size_t win_stride(size_t len) { return (len + 3) & ~size_t(3); }
+
+template <typename T, bool LW>
+__device__ __forceinline__ T* window_buf(Carve& cv, T* gwin, size_t len) {
+  if constexpr (LW) {
+    return cv.take<T>(len);
+  } else {
+    return gwin + (size_t)blockIdx.x * win_stride(len);
+  }
+}
+
 constexpr int kRedDoubles = 2 * kMaxWaves;
 
 // The sweep kernels run 4 workgroups x 8 wavefronts per CU (LDS holds four 32 KiB windows), which
@@ -38,14 +51,14 @@ constexpr int kRedDoubles = 2 * kMaxWaves;
 //   Non-orth: means stay in registers and rows stream straight to HBM (write-bound).
 //   Orth: projection is materialised in a second LDS buffer, sub-projections removed there.
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ x, int N,
                                                           const int* __restrict__ p_list, int n_p, int chunks,
                                                           unsigned flags, Tables tb, int scratch_len,
-                                                          T* __restrict__ gbuf, T* __restrict__ out) {
+                                                          T* __restrict__ gbuf, T* gwin, T* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = cv.take<T>(N);
+  T* xs = window_buf<T, LW>(cv, gwin, N);
   // orth: the whole projection is materialised here; otherwise only one period of means.
   // gbuf != nullptr: the window is too long for two LDS buffers, the second one lives in HBM.
   T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * scratch_len : cv.take<T>(scratch_len);
@@ -112,15 +125,16 @@ __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ 
 //   grid.x = W * chunks.  Fast path (no flags): wave-per-period, no workgroup barrier after
 //   the window load.  Flagged path: workgroup-cooperative full projection per period.
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
                                                       int chunks, unsigned flags, Tables tb,
                                                       const PGeom* __restrict__ geom,
                                                       const PassPlan* __restrict__ plan, int n_pass,
-                                                      T* __restrict__ gbuf, double* __restrict__ out) {
+                                                      T* __restrict__ gbuf, T* gwin,
+                                                      double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = cv.take<T>(N + kPad);
+  T* xs = window_buf<T, LW>(cv, gwin, N + kPad);
   const bool general = (flags & (kTrunc | kOrth)) && mode != 2;
   T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
@@ -141,14 +155,14 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     if (mode == 2) {
-      wave_sweep<T, true>(xs, N, geom, pa + wv, pb, nw, lane, [&](double v, int p) {
+      wave_sweep<T, true, LW>(xs, N, geom, pa + wv, pb, nw, lane, [&](double v, int p) {
         if ((lane & 7) == 0) orow[p - p_lo] = v;
       });
     } else {
       // norm modes: the workgroups of a window split the pass plan, not the period range
       const int pper = (n_pass + chunks - 1) / chunks;
       const int i0 = c * pper, i1 = min(n_pass, i0 + pper);
-      wave_sweep_plan<T>(xs, N, geom, plan, i0 + wv, i1, nw, lane, [&](double v, int p) {
+      wave_sweep_plan<T, LW>(xs, N, geom, plan, i0 + wv, i1, nw, lane, [&](double v, int p) {
         if ((lane & 7) == 0) orow[p - p_lo] = periodic_norm_from_sq(v, N, mode == 1 ? p : 0);
       });
     }
@@ -164,12 +178,12 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // m_best step 1  (Periods.py:494-537): repeat { all-p sweep, argmax, subtract } until `num`
 // distinct periods are found.  One workgroup per window, one launch per window batch.
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
                                                         const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
-                                                        T* __restrict__ gbuf,
+                                                        T* __restrict__ gbuf, T* gwin,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, T* __restrict__ bases_out,
                                                         double* __restrict__ dnorm_out,
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
                                                         int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N + kPad);
+  T* work = window_buf<T, LW>(cv, gwin, N + kPad);
   const bool general = flags & (kTrunc | kOrth);
   T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       // directly and the square roots and divisions are evaluated only when two candidates are
       // within rounding distance of each other -- and once per lane at the end.
       double best_ss = 0.0;
-      wave_sweep_plan<T>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
+      wave_sweep_plan<T, LW>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
         const bool skipped = (skip[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u;
         if (skipped || !(ss > 0.0)) return;
         bool take = bestp == 0;
@@ -350,16 +364,17 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // (:569-572), no advance of i after a split (:581-594).  One workgroup per window.
 // norms_io holds raw norms on entry and powers (norms / ||data||, :600) on exit.
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
                                                         Tables tb, const PGeom* __restrict__ geom, int max_fac,
-                                                        T* __restrict__ gbuf, uint32_t* __restrict__ periods_io,
+                                                        T* __restrict__ gbuf, T* gwin,
+                                                        uint32_t* __restrict__ periods_io,
                                                         double* __restrict__ norms_io, T* __restrict__ bases_io,
                                                         const double* __restrict__ dnorm,
                                                         const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* rowbuf = cv.take<T>(N + kPad);
+  T* rowbuf = window_buf<T, LW>(cv, gwin, N + kPad);
   T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
   double* norms = cv.take<double>(num);
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamm
       // one wavefront per factor: ||P_f row||^2 = sum_j S_f[j]^2 / cnt_f[j]
       for (int k = a + wv; k < b; k += nw) {
         const int f = tb.fac_q[k];
-        const double ss = wave_sum(wave_partial<T, false>(rowbuf, N, f, geom[f], lane));
+        const double ss = wave_sum(wave_partial<T, false, LW>(rowbuf, N, f, geom[f], lane));
         if (lane == 0) fvals[k - a] = periodic_norm_from_sq(ss, N, gdiv);
       }
       __syncthreads();
@@ -478,17 +493,17 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamm
 // ======================================================================================
 constexpr int kS2LBatch = 64;  // periods screened speculatively per round (8 waves x 8 periods)
 
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
                                                            int n_periods, unsigned flags, Tables tb,
                                                            const PGeom* __restrict__ geom, T* __restrict__ gbuf,
-                                                           int cap, int* __restrict__ counts,
+                                                           T* gwin, int cap, int* __restrict__ counts,
                                                            int* __restrict__ periods_out,
                                                            double* __restrict__ powers_out,
                                                            T* __restrict__ bases_out, int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N + kPad);
+  T* work = window_buf<T, LW>(cv, gwin, N + kPad);
   const bool general = flags & (kTrunc | kOrth);
   T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
@@ -519,7 +534,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       // on its cancellation error, reaches the threshold is evaluated exactly below; results
       // screened beyond an accepted period are discarded and recomputed.
       const int hi = min(n_periods, p + kS2LBatch - 1);
-      wave_sweep<T, false>(work, N, geom, p + wv, hi, nw, lane, [&](double ss, int q) {
+      wave_sweep<T, false, LW>(work, N, geom, p + wv, hi, nw, lane, [&](double ss, int q) {
         if ((lane & 7) == 0) psq[q - p] = ss;
       });
       __syncthreads();
@@ -605,18 +620,18 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // ======================================================================================
 // Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_best_correlation(const T* __restrict__ x, int N, int num,
                                                              int max_length, double ratio, unsigned flags,
                                                              Tables tb, const PGeom* __restrict__ geom,
-                                                             T* __restrict__ gbuf,
+                                                             T* __restrict__ gbuf, T* gwin,
                                                              uint32_t* __restrict__ periods_out,
                                                              double* __restrict__ norms_out,
                                                              T* __restrict__ bases_out,
                                                              int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N + kPad);
+  T* work = window_buf<T, LW>(cv, gwin, N + kPad);
   const bool general = flags & (kTrunc | kOrth);
   T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
@@ -646,7 +661,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       // argmax over (p, s) of |sum(x[s::p])|, strict '>' in p-major order (:324-331)
       double best = 0.0;
       int bestp = 0;
-      wave_sweep<T, true>(work, N, geom, 2 + wv, max_length - 1, nw, lane, [&](double v, int p) {
+      wave_sweep<T, true, LW>(work, N, geom, 2 + wv, max_length - 1, nw, lane, [&](double v, int p) {
         if (v > best) {
           best = v;
           bestp = p;
@@ -726,14 +741,13 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // ======================================================================================
 constexpr int kRamBlock = 1024;
 
-template <typename T, int C, int U>
+template <typename T, int C, int U, bool LW>
 __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0,
                                                  int lane, double* __restrict__ sbuf) {
-  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;
   double s[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) s[c] = 0.0;
-  fold_rows<T, C, U>((lds_ptr)xs + lane + 64 * c0, p, rows - 1, s);
+  fold_rows<T, C, U, LW>(Win<T, LW>::cast(xs) + lane + 64 * c0, p, rows - 1, s);
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int j = 64 * (c0 + c) + lane;
@@ -743,16 +757,16 @@ __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p
   }
 }
 
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x, int N, int q_lo, int q_hi,
                                                          const PGeom* __restrict__ geom,
                                                          const int* __restrict__ pr_off,
                                                          const int* __restrict__ pr_d,
-                                                         const int* __restrict__ totient,
+                                                         const int* __restrict__ totient, T* gwin,
                                                          double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = cv.take<T>(N + kPad);
+  T* xs = window_buf<T, LW>(cv, gwin, N + kPad);
   const int nw = blockDim.x >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
@@ -775,11 +789,11 @@ __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x
     if (q >= 64) {
       const int nchunks = (q + 63) >> 6;
       int c0 = 0;
-      for (; c0 + 4 <= nchunks; c0 += 4) fold_store_group<T, 4, 2>(xs, q, rows, nfull, c0, lane, sbuf);
+      for (; c0 + 4 <= nchunks; c0 += 4) fold_store_group<T, 4, 2, LW>(xs, q, rows, nfull, c0, lane, sbuf);
       switch (nchunks - c0) {
-        case 3: fold_store_group<T, 3, 2>(xs, q, rows, nfull, c0, lane, sbuf); break;
-        case 2: fold_store_group<T, 2, 4>(xs, q, rows, nfull, c0, lane, sbuf); break;
-        case 1: fold_store_group<T, 1, 8>(xs, q, rows, nfull, c0, lane, sbuf); break;
+        case 3: fold_store_group<T, 3, 2, LW>(xs, q, rows, nfull, c0, lane, sbuf); break;
+        case 2: fold_store_group<T, 2, 4, LW>(xs, q, rows, nfull, c0, lane, sbuf); break;
+        case 1: fold_store_group<T, 1, 8, LW>(xs, q, rows, nfull, c0, lane, sbuf); break;
         default: break;
       }
     } else {
@@ -933,7 +947,7 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     double best = 0.0;
     int bestp = 0;
     double best_ss = 0.0;  // same lazy comparison as in k_mbest_step1 (gamma norm: ss / p)
-    wave_sweep_plan<T>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
+    wave_sweep_plan<T, true>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
       if (!(ss > 0.0)) return;
       bool take = bestp == 0;
       if (!take) {

@@ -196,6 +196,49 @@ def test_long_windows_spill_second_buffer_to_hbm(eng):
     assert eng.max_window(np.float64, True, True) >= n
 
 
+def test_windows_longer_than_lds_stream_from_hbm(eng):
+    """N = 32768 fp64 (256 KiB) exceeds the 160 KiB LDS: the window itself lives in a per-workgroup
+    HBM workspace and the same fold code reads it through L2 (kernels' <T, false> instantiations)."""
+    from pyperiod_amd import _ffi
+
+    n = 32768
+    assert n > eng.max_window()
+    x = multi_sinusoid_batch(500, 2, n)
+    plist = [1, 3, 64, 97, 1260, 4099, 20000]
+    out = eng.project_batch(x, plist)
+    for w in range(2):
+        for k, p in enumerate(plist):
+            ref = po.project(x[w], p)
+            assert np.array_equal(out[w, k], ref) if p > 1 else rel_err(out[w, k], ref) < 1e-12, p
+    out = eng.project_batch(x[:1], [36, 1260], True, True)
+    for k, p in enumerate([36, 1260]):
+        assert np.array_equal(out[0, k], po.project(x[0], p, True, True)), p
+    hi = 700
+    sw = eng.sweep(x, 2, hi, _ffi.PH_SWEEP_NORM)
+    sg = eng.sweep(x, 2, hi, _ffi.PH_SWEEP_NORM_GAMMA)
+    sm = eng.sweep(x[:1], 2, 200, _ffi.PH_SWEEP_MAXABS)
+    so = eng.sweep(x[:1], 2, 60, _ffi.PH_SWEEP_NORM, False, True)
+    for w in range(2):
+        assert rel_err(sw[w], po.sweep_norms(x[w], 2, hi)) < TOL
+        assert rel_err(sg[w], po.sweep_norms(x[w], 2, hi, gamma=True)) < TOL
+    assert rel_err(sm[0], po.sweep_maxabs(x[0], 2, 200)) < TOL
+    assert rel_err(so[0], po.sweep_norms(x[0], 2, 60, orth=True)) < TOL
+    per, pw, bs, st = eng.m_best(x, 3, 500)
+    for w in range(2):
+        rper, rpw, rbs = po.m_best(x[w], 3, 500)
+        assert st[w] == 0 and np.array_equal(per[w], rper)
+        assert rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL
+    counts, sper, spw, sbs, _ = eng.small_to_large(x[:1], 0.05, 300)
+    lper, lpw, lbs = po.small_to_large(x[0], 0.05, 300)
+    assert list(sper[0, : counts[0]]) == lper and rel_err(spw[0, : counts[0]], lpw) < TOL
+    assert rel_err(sbs[0, : counts[0]], np.array(lbs)) < TOL
+    bper, bnr, bbs, bst = eng.best_correlation(x[:1], 2, 300)
+    rper, rnr, rbs = po.best_correlation(x[0], 2, 300)
+    assert np.array_equal(bper[0], rper) and rel_err(bnr[0], rnr) < TOL and rel_err(bbs[0], rbs) < TOL
+    ram = eng.ramanujan_norms(x[:1], 2, 128)
+    assert rel_err(ram[0], po.ramanujan_norms_folded(x[0], 2, 128)) < 1e-9
+
+
 def test_batch_interface_edges(eng):
     from pyperiod_amd import Periods, _ffi
 
@@ -210,7 +253,7 @@ def test_batch_interface_edges(eng):
     x = multi_sinusoid_batch(0, 1, nmax)
     assert np.array_equal(eng.project_batch(x, [977])[0, 0], po.project(x[0], 977))
     with pytest.raises(ValueError):
-        eng.project_batch(np.zeros((1, nmax + 4096)), [3])  # does not fit LDS: PH_E_ARG
+        eng.orth_powers(np.zeros((1, nmax + 4096)), 8)  # autocorrelation needs the window in LDS: PH_E_ARG
     with pytest.raises(ValueError):
         eng.project_batch(np.zeros((1, 8)), [0])
     with pytest.raises(ValueError):
