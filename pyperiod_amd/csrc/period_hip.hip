@@ -145,6 +145,13 @@ int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n
     for (int d = 1; d <= m; d *= 2) covered[(size_t)d * p] = 1;
     host.push_back(ph::PassPlan{p, m});
   }
+  if (const char* only = std::getenv("PH_PLAN_ONLY_M")) {  // profiling aid: keep one pass type (results incomplete)
+    const int want = std::atoi(only);
+    std::vector<ph::PassPlan> kept;
+    for (const auto& e : host)
+      if (e.m == want) kept.push_back(e);
+    host.swap(kept);
+  }
   PH_HIP(hipStreamSynchronize(c->stream));
   PH_TRY(ensure(c, c->plan, std::max<size_t>(1, host.size()) * sizeof(ph::PassPlan)));
   if (!host.empty())
