@@ -631,7 +631,16 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
                 carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8);
   void *gbuf1, *gbuf2;
   PH_TRY(place_second_buffer(c, &lds1, general, (size_t)N * sz, W, &gbuf1));
-  PH_TRY(place_second_buffer(c, &lds2, true, (size_t)N * sz, W, &gbuf2));
+  // step 2 materialises a projection only when a row is split (rare) or in the trunc/orth modes:
+  // in plain mode that buffer always lives in the HBM workspace, which lets four workgroups of
+  // eight wavefronts share a CU instead of two of four
+  if (general) {
+    PH_TRY(place_second_buffer(c, &lds2, true, (size_t)N * sz, W, &gbuf2));
+  } else {
+    lds2 -= carve_bytes(N, sz);
+    PH_TRY(ensure(c, c->buf[B_GBUF], (size_t)W * N * sz));
+    gbuf2 = c->buf[B_GBUF].p;
+  }
   void *gwin1, *gwin2;  // the two kernels run back to back on one stream and may share the workspace
   PH_TRY(place_window(c, &lds1, N + kPad, sz, W, &gwin1));
   PH_TRY(place_window(c, &lds2, N + kPad, sz, W, &gwin2));
@@ -675,7 +684,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     auto kernel = ph::k_mbest_step2<T, decltype(lw)::value>;
     PH_TRY(allow_lds(kernel, lds2));
     ProfScope ps_(c, "k_mbest_step2");
-    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds2, c->stream, N, num, gamma, max_length, kflags, tb, geom,
+    hipLaunchKernelGGL(kernel, grid, dim3(general ? kBlock : c->sweep_block), lds2, c->stream, N, num, gamma,
+                       max_length, kflags, tb, geom,
                        max_fac, (T*)gbuf2, (T*)gwin2, (uint32_t*)dper, (double*)dpow, (T*)dbases, dnorm,
                        (const int*)dstat);
     return (int)PH_OK;

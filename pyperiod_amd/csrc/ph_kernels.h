@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // norms_io holds raw norms on entry and powers (norms / ||data||, :600) on exit.
 // ======================================================================================
 template <typename T, bool LW>
-__global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
                                                         Tables tb, const PGeom* __restrict__ geom, int max_fac,
                                                         T* __restrict__ gbuf, T* gwin,
                                                         uint32_t* __restrict__ periods_io,
@@ -399,11 +399,15 @@ __global__ __launch_bounds__(kBlock) void k_mbest_step2(int N, int num, int gamm
   int i = (status[w] == 0) ? 0 : num;  // a window whose step 1 failed is passed through
   while (i < num) {
     const int per = (int)periods[i];
+    const int a = tb.fac_off[per], b = tb.fac_off[per + 1];
+    if (a == b) {  // no proper divisor (a prime): nothing to test, the row is not even read
+      i += 1;
+      continue;
+    }
     load_window(bases + (int64_t)i * N, rowbuf, N);
     __syncthreads();
     double top = 0.0, last = 0.0;
     int topf = -1;
-    const int a = tb.fac_off[per], b = tb.fac_off[per + 1];
     if (!general) {
       // one wavefront per factor: ||P_f row||^2 = sum_j S_f[j]^2 / cnt_f[j]
       for (int k = a + wv; k < b; k += nw) {
