@@ -1027,8 +1027,18 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   size_t lds = carve_bytes(N + kPad, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
                carve_bytes(kMaxWaves, 4) + 2 * carve_bytes(ph::kQoMaxBlocks, 4) +
                carve_bytes(ph::kQoMaxBlocks + 1, 4) + carve_bytes(ph::kQoMaxBlocks, 8) +
-               carve_bytes((max_length + 32) / 32, 4) + carve_bytes(kcap, 8);
+               carve_bytes((max_length + 32) / 32, 4) + carve_bytes(kcap, 8) +
+               carve_bytes((size_t)ph::kQoTile * ph::kQoPanelMax, 8) +
+               carve_bytes((size_t)kMaxWaves * ph::kQoPanelMax, 8);
   PH_TRY(check_lds(c, lds, N, "ph_qo_find_periods"));
+  // LDS panel of the blocked Cholesky: as wide as the remaining LDS allows (<= kQoPanelMax columns)
+  const size_t ldp = (size_t)((kcap + 1) | 1);
+  const size_t room = (size_t)c->lds_limit > lds + 64 ? (size_t)c->lds_limit - lds - 64 : 0;
+  const int nbw = (int)std::min<size_t>(ph::kQoPanelMax, room / (ldp * 8));
+  if (nbw < 1)
+    return fail(PH_E_ARG, "ph_qo_find_periods: N=%d and kcap=%d leave no LDS for a Cholesky panel (limit %d B)", N,
+                kcap, c->lds_limit);
+  lds += carve_bytes(ldp * nbw, 8);
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, max_length, &geom));
   const ph::PassPlan* plan;
@@ -1070,7 +1080,7 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
     {
       ProfScope ps_(c, "k_qo_find");
       hipLaunchKernelGGL(ph::k_qo_find<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, num,
-                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap,
+                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, nbw,
                          (double*)c->buf[B_WS1].p, (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt,
                          (double*)dwts, (double*)dres, (int*)dstat);
     }
@@ -1079,7 +1089,7 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
     {
       ProfScope ps_(c, "k_qo_find");
       hipLaunchKernelGGL(ph::k_qo_find<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, num,
-                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap,
+                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, nbw,
                          (double*)c->buf[B_WS1].p, (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt,
                          (double*)dwts, (float*)dres, (int*)dstat);
     }

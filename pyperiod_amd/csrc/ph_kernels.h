@@ -893,12 +893,15 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 // ======================================================================================
 constexpr int kQoMaxBlocks = 64;
 
+constexpr int kQoPanelMax = 16;  // widest LDS panel of the blocked Cholesky
+constexpr int kQoTile = 64;      // finished columns staged per update step
+
 template <typename T>
 __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
                                                         int p_lo, int p_hi, const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
                                                         const int* __restrict__ phi, const int* __restrict__ div_off,
-                                                        const int* __restrict__ div_q, int kcap,
+                                                        const int* __restrict__ div_q, int kcap, int nbw,
                                                         double* __restrict__ ws_all, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, int* __restrict__ keeps_out,
                                                         int* __restrict__ counts_out, double* __restrict__ weights_out,
@@ -915,6 +918,10 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
   double* bnorm = cv.take<double>(kQoMaxBlocks);
   uint32_t* seen = cv.take<uint32_t>((p_hi + 32) / 32);  // running divisor set R (QOPeriods.py:832-835)
   double* yv = cv.take<double>(kcap);  // solve vector
+  const int ldp = (kcap + 1) | 1;                                // panel column stride (odd: no bank conflicts)
+  double* pan = cv.take<double>((size_t)ldp * nbw);             // panel of the blocked factorisation
+  double* tile = cv.take<double>((size_t)kQoTile * kQoPanelMax);  // block row of L for the panel update
+  double* dsum = cv.take<double>((size_t)kMaxWaves * kQoPanelMax);
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1013,24 +1020,50 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     }
     __syncthreads();
     const int K = row0 + keep;
-    // ---- Gram rows of the new block: G[(a,i),(nb,j)] = #{n < N : n = i (mod p_a), n = j (mod p)}
+    // ---- Gram columns of the new block: G[(a,i),(nb,j)] = #{n < N : n = i (mod p_a), n = j (mod p)}.
+    //      Along n = j, j+p, j+2p, ... the residue mod p_a cycles with period p_a / gcd(p_a, p), so
+    //      each entry is a closed-form count; no read-modify-write on HBM.
+    for (int e = tid; e < K * keep; e += blockDim.x) G[(int64_t)(row0 + e / K) * kcap + e % K] = 0.0;
+    __threadfence_block();
+    __syncthreads();
     for (int j = tid; j < keep; j += blockDim.x) {
       double* col = G + (int64_t)(row0 + j) * kcap;  // column (nb, j); thread j owns it
-      for (int r = 0; r < K; ++r) col[r] = 0.0;
+      const int terms = (N - 1 - j) / bestp + 1;     // samples n = j (mod p) below N
       for (int b = 0; b <= nb; ++b) {
         const int pa = bper[b], ka = bkeep[b], oa = boff[b];
+        int g = pa, h = bestp % pa;
+        while (h != 0) {
+          const int t = g % h;
+          g = h;
+          h = t;
+        }
+        const int cycle = pa / g;
         int i = j % pa;
         const int step = bestp % pa;
-        for (int n = j; n < N; n += bestp) {
-          if (i < ka) col[oa + i] += 1.0;
+        const int lim = cycle < terms ? cycle : terms;
+        for (int t0 = 0; t0 < lim; ++t0) {
+          if (i < ka) col[oa + i] = (double)((terms - 1 - t0) / cycle + 1);
           i += step;
           if (i >= pa) i -= pa;
         }
       }
-      // right-hand side: fold of the data (QOPeriods.py:782), rows in order
-      double s = 0.0;
-      for (int n = j; n < N; n += bestp) s += (double)data[n];
-      rhs[row0 + j] = s;
+      // right-hand side: fold of the data (QOPeriods.py:782), rows in order, eight loads ahead
+      const T* ptr = data + j;
+      double sj = 0.0;
+      int r = 0;
+      for (; r + 8 <= terms; r += 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ptr[(int64_t)u * bestp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sj += (double)v[u];
+        ptr += (int64_t)8 * bestp;
+      }
+      for (; r < terms; ++r) {
+        sj += (double)ptr[0];
+        ptr += bestp;
+      }
+      rhs[row0 + j] = sj;
     }
     __threadfence_block();
     __syncthreads();
@@ -1041,51 +1074,109 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     }
     __threadfence_block();
     __syncthreads();
-    // ---- Cholesky G = L L^T (lower, column-major), then L y = rhs, L^T w = y
-    for (int e = tid; e < K * K; e += blockDim.x) {
-      const int r = e % K, cidx = e / K;
-      if (r >= cidx) L[(int64_t)cidx * kcap + r] = G[(int64_t)cidx * kcap + r];
-    }
-    __threadfence_block();
-    __syncthreads();
+    // ---- G = L L^T, L y = rhs, L^T w = y.  Blocked left-looking Cholesky of the augmented matrix
+    //      [G rhs; rhs^T .] (its last row is y): a panel of <= nbw columns (rows J..K-1 plus the rhs
+    //      row) lives in LDS, the finished columns are streamed from the HBM workspace once per panel
+    //      (coalesced, read-only), and the panel itself is factored at LDS speed.
     bool singular = false;
-    for (int k = 0; k < K; ++k) {
-      const double piv = L[(int64_t)k * kcap + k];
-      if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
-        singular = true;
-        break;
+    for (int J = 0; J < K && !singular; J += nbw) {
+      const int jb = min(nbw, K - J);
+      const int nr = K - J + 1;  // rows J .. K-1 and the rhs row
+      for (int e = tid; e < nr * jb; e += blockDim.x) {
+        const int cc = e / nr, rr = e % nr, r = J + rr;
+        pan[cc * ldp + rr] = r < K ? (rr >= cc ? G[(int64_t)(J + cc) * kcap + r] : 0.0) : rhs[J + cc];
       }
-      const double d = sqrt(piv);
       __syncthreads();
-      for (int r = k + tid; r < K; r += blockDim.x) L[(int64_t)k * kcap + r] /= d;
-      __threadfence_block();
-      __syncthreads();
-      // trailing update: column c (> k) -= L[c][k] * L[:, k]
-      const int rem = K - k - 1;
-      for (int e = tid; e < rem * rem; e += blockDim.x) {
-        const int cc = k + 1 + e / rem, rr = k + 1 + e % rem;
-        if (rr >= cc) L[(int64_t)cc * kcap + rr] -= L[(int64_t)k * kcap + rr] * L[(int64_t)k * kcap + cc];
+      for (int t0 = 0; t0 < J; t0 += kQoTile) {
+        const int tn = min(kQoTile, J - t0);
+        for (int e = tid; e < tn * kQoPanelMax; e += blockDim.x) {
+          const int tt = e / kQoPanelMax, cc = e % kQoPanelMax;
+          tile[e] = cc < jb ? L[(int64_t)(t0 + tt) * kcap + J + cc] : 0.0;
+        }
+        __syncthreads();
+        for (int rr = tid; rr < nr; rr += blockDim.x) {
+          double acc[kQoPanelMax];
+#pragma unroll
+          for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = 0.0;
+          const bool is_rhs = rr == nr - 1;
+          const double* src = is_rhs ? yv + t0 : L + (int64_t)t0 * kcap + J + rr;
+          const int64_t stride = is_rhs ? 1 : kcap;
+          for (int tt = 0; tt < tn; ++tt) {
+            const double a = src[tt * stride];
+#pragma unroll
+            for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = fma(a, tile[tt * kQoPanelMax + cc], acc[cc]);
+          }
+#pragma unroll
+          for (int cc = 0; cc < kQoPanelMax; ++cc)
+            if (cc < jb) pan[cc * ldp + rr] -= acc[cc];
+        }
+        __syncthreads();
+      }
+      for (int cc = 0; cc < jb; ++cc) {
+        const double piv = pan[cc * ldp + cc];
+        if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
+          singular = true;
+          break;
+        }
+        const double d = sqrt(piv);
+        __syncthreads();
+        for (int rr = cc + tid; rr < nr; rr += blockDim.x) pan[cc * ldp + rr] /= d;
+        __syncthreads();
+        const int span = nr - cc - 1;
+        for (int e = tid; e < (jb - cc - 1) * span; e += blockDim.x) {
+          const int c2 = cc + 1 + e / span, rr = cc + 1 + e % span;
+          if (rr >= c2) pan[c2 * ldp + rr] -= pan[cc * ldp + rr] * pan[cc * ldp + c2];
+        }
+        __syncthreads();
+      }
+      if (singular) break;
+      for (int e = tid; e < nr * jb; e += blockDim.x) {
+        const int cc = e / nr, rr = e % nr, r = J + rr;
+        if (rr >= cc) {
+          if (r < K)
+            L[(int64_t)(J + cc) * kcap + r] = pan[cc * ldp + rr];
+          else
+            yv[J + cc] = pan[cc * ldp + rr];
+        }
       }
       __threadfence_block();
       __syncthreads();
     }
     if (singular) break;  // go back one iteration and stop (QOPeriods.py:552-559)
-    // L y = rhs, then L^T w = y: column sweeps, the vector lives in LDS
-    for (int r = tid; r < K; r += blockDim.x) yv[r] = rhs[r];
-    __syncthreads();
-    for (int cidx = 0; cidx < K; ++cidx) {
-      const double yc = yv[cidx] / L[(int64_t)cidx * kcap + cidx];
+    // L^T w = y, panels from the last one back: the rows below a panel are already final, their
+    // contribution is one workgroup reduction per panel; the diagonal block is solved by thread 0
+    for (int jend = K; jend > 0;) {
+      const int jb = min(nbw, jend), J = jend - jb, nr = K - J;
+      for (int e = tid; e < nr * jb; e += blockDim.x) {
+        const int cc = e / nr, rr = e % nr;
+        if (rr >= cc) pan[cc * ldp + rr] = L[(int64_t)(J + cc) * kcap + J + rr];
+      }
       __syncthreads();
-      for (int r = cidx + 1 + tid; r < K; r += blockDim.x) yv[r] -= L[(int64_t)cidx * kcap + r] * yc;
-      if (tid == 0) yv[cidx] = yc;
+      double acc[kQoPanelMax];
+#pragma unroll
+      for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = 0.0;
+      for (int rr = jb + tid; rr < nr; rr += blockDim.x) {
+        const double wr = yv[J + rr];
+#pragma unroll
+        for (int cc = 0; cc < kQoPanelMax; ++cc)
+          if (cc < jb) acc[cc] = fma(pan[cc * ldp + rr], wr, acc[cc]);
+      }
+#pragma unroll
+      for (int cc = 0; cc < kQoPanelMax; ++cc) {
+        const double v = wave_sum(acc[cc]);
+        if (lane == 0) dsum[wv * kQoPanelMax + cc] = v;
+      }
       __syncthreads();
-    }
-    for (int cidx = K - 1; cidx >= 0; --cidx) {
-      const double wc = yv[cidx] / L[(int64_t)cidx * kcap + cidx];
+      if (tid == 0) {
+        for (int cc = jb - 1; cc >= 0; --cc) {
+          double v = yv[J + cc];
+          for (int i = 0; i < nw; ++i) v -= dsum[i * kQoPanelMax + cc];
+          for (int c2 = cc + 1; c2 < jb; ++c2) v -= pan[cc * ldp + c2] * yv[J + c2];
+          yv[J + cc] = v / pan[cc * ldp + cc];
+        }
+      }
       __syncthreads();
-      for (int r = tid; r < cidx; r += blockDim.x) yv[r] -= L[(int64_t)r * kcap + cidx] * wc;
-      if (tid == 0) yv[cidx] = wc;
-      __syncthreads();
+      jend = J;
     }
     nb += 1;
     // ---- reconstruction A^T w (QOPeriods.py:795) and the new residual
