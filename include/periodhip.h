@@ -155,6 +155,21 @@ int ph_best_correlation(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N,
                         unsigned flags, uint32_t* periods, double* norms, void* bases,
                         int32_t* status);
 
+/* ---- Periods.best_frequency (Periods.py:351-398) ----------------------------------------
+ * num times: k = argmax |rfft(residual, win_size)| (first maximum, Periods.py:386-389),
+ * p = round(2 win_size / k) (:390-391, round-half-even), project, store, subtract (:392-397).
+ * The spectrum is a direct real DFT over the first min(N, win_size) samples (any win_size, no FFT
+ * library), twiddles from a float64 table; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH
+ * (orth tables must cover p <= 2 win_size).  win_size < 1 = N (:381-382).
+ * periods (W, num) uint32; powers (W, num) float64 = norm / ||data|| (:397-399); bases
+ * (W, num, N).  status PH_ST_NO_PERIOD: the spectral peak was bin 0 (or the spectrum NaN) at
+ * some iteration -- the reference divides by zero there and raises OverflowError; rows from that
+ * iteration on are zero. */
+int ph_best_frequency(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int win_size,
+                      int num, const int32_t* orth_off, const int32_t* orth_q, int table_max_p,
+                      unsigned flags, uint32_t* periods, double* powers, void* bases,
+                      int32_t* status);
+
 /* ---- RamanujanPeriods.find_periods (RamanujanPeriods.py:67-86 with :124-169) ------------
  * out (W, q_hi + 1) float64; entries below q_lo are zero (RamanujanPeriods.py:71).
  * Evaluated in float64 through the folded form (fold to S_q, Moebius-filter with the

@@ -106,27 +106,21 @@ class Periods:
         return (per, nr, bs) if batched else (per[0], nr[0], bs[0])
 
     def best_frequency(self, data, win_size: int = None, num: int = 5):
-        """Best-frequency (Periods.py:351-398): the spectral peak is picked with numpy's
-        rfft on the host (as in the reference); every projection and norm runs on the GPU."""
-        x = _as_window(data)
+        """Best-frequency (Periods.py:351-398) on the GPU: spectral peak by a direct real DFT,
+        p = round(2 win_size / k), project, subtract -- one call for all `num` rounds."""
+        x, batched = self._batch(data)
+        n = x.shape[1]
         if win_size is None:
-            win_size = len(x)
-        elif win_size < len(x):
+            win_size = n
+        elif win_size < n:
             warn("win_size is smaller than the input signal length. It will be truncated and information will be lost.")
-        eng = default_engine()
-        periods = np.zeros(num, dtype=np.uint32)
-        norms = np.zeros(num)
-        bases = np.zeros((num, len(x)))
-        work = x.copy()
-        for i in range(num):
-            mags = np.abs(np.fft.rfft(work, win_size))
-            p = int(np.round((2 * win_size) / np.argmax(mags)))
-            base = eng.project_batch(work[None, :], [p], self._trunc_to_integer_multiple, self._orthogonalize)[0, 0]
-            periods[i] = p
-            norms[i] = eng.periodic_norm(base[None, :])[0]
-            bases[i] = base
-            work = work - base
-        return (periods, norms / eng.periodic_norm(x[None, :])[0], bases)
+        per, pw, bs, st = default_engine().best_frequency(
+            x, win_size, num, self._trunc_to_integer_multiple, self._orthogonalize
+        )
+        if np.any(np.asarray(st) != 0):
+            # the spectral peak was bin 0: the reference evaluates 2 * win_size / 0 and int(round(inf))
+            raise OverflowError("cannot convert float infinity to integer")
+        return (per, pw, bs) if batched else (per[0], pw[0], bs[0])
 
     def m_best(self, data, num: int = 5, max_length: int = None, min_length: int = 2):
         """M-best (Periods.py:408-430)."""

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ph_profile_read": [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)],
     "ph_small_to_large": [_vp, _vp, _i, _i64, _i, _d, _i, _pi32, _pi32, _i, _u, _i, _vp, _vp, _vp, _vp, _vp],
     "ph_best_correlation": [_vp, _vp, _i, _i64, _i, _i, _i, _d, _pi32, _pi32, _i, _u, _vp, _vp, _vp, _vp],
+    "ph_best_frequency": [_vp, _vp, _i, _i64, _i, _i, _i, _pi32, _pi32, _i, _u, _vp, _vp, _vp, _vp],
     "ph_ramanujan_norms": [_vp, _vp, _i, _i64, _i, _i, _i, _u, _vp],
     "ph_dict_project": [_vp, _vp, _vp, _i, _i, _u, _vp],
     "ph_qo_find_periods": [_vp, _vp, _i, _i64, _i, _i, _d, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -70,6 +70,8 @@ struct ph_ctx {
   // per-period fold geometry for the tuned sweeps, cached for the last (N, max_p)
   DevBuf geom;
   int geom_n = -1, geom_max_p = -1;
+  DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
+  int twid_len = -1;
   DevBuf plan;  // pass plan of the norm sweeps, cached for the last (p_lo, p_hi)
   int plan_lo = -1, plan_hi = -1, plan_n = 0;
   int plan_max_m = 4;  // largest row-class count a pass may use (PH_PLAN_MAX_M overrides: 1, 2 or 4)
@@ -444,6 +446,7 @@ int ph_destroy(ph_ctx* c) {
     if (t.dev.p) (void)hipFree(t.dev.p);
   if (c->geom.p) (void)hipFree(c->geom.p);
   if (c->plan.p) (void)hipFree(c->plan.p);
+  if (c->twid.p) (void)hipFree(c->twid.p);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -791,6 +794,65 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
     return (int)PH_OK;
   }));
   PH_TRY(launch_check("k_best_correlation"));
+  return st.finish();
+}
+
+// ----------------------------------------------------------------------------- best_frequency
+int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int win_size, int num,
+                      const int32_t* orth_off, const int32_t* orth_q, int table_max_p, unsigned flags,
+                      uint32_t* periods, double* powers, void* bases, int32_t* status) {
+  PH_TRY(check_common(c, x, dtype, W, N));
+  if (!periods || !powers || !bases || !status) return fail(PH_E_ARG, "output pointer is NULL");
+  if (num < 1) return fail(PH_E_ARG, "num=%d must be >= 1", num);
+  const int L = win_size < 1 ? N : win_size;  // Periods.py:381-382
+  if (L < 2 || L > (1 << 24)) return fail(PH_E_ARG, "win_size=%d out of range", L);
+  PH_HIP(hipSetDevice(c->device));
+  const size_t sz = elem_size(dtype);
+  size_t lds = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+               carve_bytes(kMaxWaves, 4);
+  void* gbuf;
+  PH_TRY(place_second_buffer(c, &lds, true, (size_t)N * sz, W, &gbuf));
+  PH_TRY(check_lds(c, lds, N, "ph_best_frequency"));
+  ph::Tables tb{};
+  PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, 2 * L, &tb));
+  if (c->twid_len != L) {  // twiddles in float64, argument reduced exactly: k / L is a fraction of a turn
+    std::vector<double> tw(2 * (size_t)L);
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int k = 0; k < L; ++k) {
+      const long double a = two_pi * (long double)k / (long double)L;
+      tw[2 * (size_t)k] = (double)std::cos(a);
+      tw[2 * (size_t)k + 1] = (double)std::sin(a);
+    }
+    PH_HIP(hipStreamSynchronize(c->stream));
+    PH_TRY(ensure(c, c->twid, tw.size() * sizeof(double)));
+    PH_HIP(hipMemcpyAsync(c->twid.p, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PH_HIP(hipStreamSynchronize(c->stream));
+    c->twid_len = L;
+  }
+  Stage st(c, flags);
+  const void* dx;
+  void *dper, *dpow, *dbases, *dstat;
+  PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
+  PH_TRY(st.out(B_OUT0, periods, (size_t)W * num * sizeof(uint32_t), &dper));
+  PH_TRY(st.out(B_OUT1, powers, (size_t)W * num * sizeof(double), &dpow));
+  PH_TRY(st.out(B_OUT2, bases, (size_t)W * num * N * sz, &dbases));
+  PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
+  const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  const dim3 grid((unsigned)W);
+  if (dtype == PH_F64) {
+    PH_TRY(allow_lds(ph::k_best_frequency<double>, lds));
+    ProfScope ps_(c, "k_best_frequency");
+    hipLaunchKernelGGL(ph::k_best_frequency<double>, grid, dim3(kBlockWide), lds, c->stream, (const double*)dx, N, L,
+                       num, kflags, tb, (const double2*)c->twid.p, (double*)gbuf, (uint32_t*)dper, (double*)dpow,
+                       (double*)dbases, (int*)dstat);
+  } else {
+    PH_TRY(allow_lds(ph::k_best_frequency<float>, lds));
+    ProfScope ps_(c, "k_best_frequency");
+    hipLaunchKernelGGL(ph::k_best_frequency<float>, grid, dim3(kBlockWide), lds, c->stream, (const float*)dx, N, L,
+                       num, kflags, tb, (const double2*)c->twid.p, (float*)gbuf, (uint32_t*)dper, (double*)dpow,
+                       (float*)dbases, (int*)dstat);
+  }
+  PH_TRY(launch_check("k_best_frequency"));
   return st.finish();
 }
 

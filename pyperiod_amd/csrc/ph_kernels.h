@@ -733,6 +733,107 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 }
 
 // ======================================================================================
+// Periods.best_frequency  (Periods.py:351-398).  One workgroup per window.
+//   spectrum: thread per rfft bin k, X[k] = sum_n x[n] (cos - i sin)(2 pi k n / L) with the phase
+//   index k n mod L kept incrementally and the twiddles read from a float64 table (L2-resident);
+//   argmax |X[k]|^2, first maximum.  Then p = rint(2 L / k), project (all flag combinations),
+//   store, subtract.
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_best_frequency(const T* __restrict__ x, int N, int L, int num,
+                                                               unsigned flags, Tables tb,
+                                                               const double2* __restrict__ tw, T* __restrict__ gbuf,
+                                                               uint32_t* __restrict__ periods_out,
+                                                               double* __restrict__ powers_out,
+                                                               T* __restrict__ bases_out,
+                                                               int* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* work = cv.take<T>(N);
+  T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
+  double* red = cv.take<double>(kRedDoubles);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  T* bases = bases_out + w * (int64_t)num * N;
+  load_window(x + w * (int64_t)N, work, N);
+  __syncthreads();
+  const double data_norm = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
+  const int M = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
+  int status = 0, done = 0;
+  for (int it = 0; it < num; ++it) {
+    // ---- spectral peak
+    double best = -1.0;
+    int bestk = 0;  // bin + 1; 0 = none
+    for (int k = tid; k <= L / 2; k += blockDim.x) {
+      double re = 0.0, im = 0.0;
+      int idx = 0;
+      for (int n = 0; n < M; ++n) {
+        const double xv = (double)work[n];
+        const double2 cs = tw[idx];
+        re = fma(xv, cs.x, re);
+        im = fma(xv, cs.y, im);
+        idx += k;
+        if (idx >= L) idx -= L;
+      }
+      const double m2 = re * re + im * im;
+      if (m2 > best) {  // ascending k per thread: strict '>' keeps the first maximum
+        best = m2;
+        bestk = k + 1;
+      }
+    }
+    wave_argmax(best, bestk);
+    if (lane == 0) {
+      wbest[wv] = best;
+      wbestp[wv] = bestk;
+    }
+    __syncthreads();
+    best = -1.0;
+    bestk = 0;
+    for (int i = 0; i < nw; ++i) {
+      const double v = wbest[i];
+      const int kk = wbestp[i];
+      if (kk != 0 && (bestk == 0 || v > best || (v == best && kk < bestk))) {
+        best = v;
+        bestk = kk;
+      }
+    }
+    __syncthreads();
+    if (bestk <= 1) {  // bin 0 (or nothing comparable): 2 L / 0 in the reference
+      status = 1;
+      break;
+    }
+    const int p = (int)rint(2.0 * (double)L / (double)(bestk - 1));
+    // ---- project, store, subtract (Periods.py:392-397)
+    project_lds(work, buf, N, p, flags, tb);
+    const double nrm = periodic_norm_from_sq(block_sumsq(buf, N, red), N, 0);
+    T* brow = bases + (int64_t)it * N;
+    for (int n = tid; n < N; n += blockDim.x) {
+      const T b = buf[n];
+      brow[n] = b;
+      work[n] -= b;
+    }
+    if (tid == 0) {
+      periods_out[w * num + it] = (uint32_t)p;
+      powers_out[w * num + it] = nrm / data_norm;
+    }
+    done = it + 1;
+    __syncthreads();
+  }
+  for (int64_t n = (int64_t)done * N + tid; n < (int64_t)num * N; n += blockDim.x) bases[n] = T(0);
+  for (int k = done + tid; k < num; k += blockDim.x) {
+    periods_out[w * num + k] = 0u;
+    powers_out[w * num + k] = 0.0;
+  }
+  if (tid == 0) status_out[w] = status;
+}
+
+// ======================================================================================
 // RamanujanPeriods.find_periods  (RamanujanPeriods.py:67-86, :124-169), folded form.
 //   Rows of the reference dictionary are shifts of c_q / phi(q) (the row / max(row) at :129
 //   cancels the L2 normalisation of :168).  With S = fold of x to period q:

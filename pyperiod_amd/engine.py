@@ -277,6 +277,26 @@ class PeriodEngine:
             )
         return periods, norms, bases, status
 
+    def best_frequency(self, x, win_size=None, num=5, trunc=False, orth=False):
+        """Periods.best_frequency over a batch (Periods.py:351-398): periods (W, num) uint32, powers
+        (W, num), bases (W, num, N), status (W) -- PH_ST_NO_PERIOD where the reference raises."""
+        x, code, W, N, fl, mk = self._prep(x)
+        win_size = N if win_size is None else int(win_size)
+        num = int(num)
+        keep = self._orth(orth, 2 * max(win_size, 1))
+        periods = mk.empty((W, num), np.uint32)
+        powers = mk.empty((W, num), np.float64)
+        bases = mk.empty((W, num, N), self._np_dtype(code))
+        status = mk.empty((W,), np.int32)
+        with self._lock:
+            _ffi.check(
+                self._lib.ph_best_frequency(
+                    self._ctx, mk.addr(x), code, W, N, win_size, num, keep[2], keep[3], keep[4],
+                    fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status),
+                )
+            )
+        return periods, powers, bases, status
+
     def ramanujan_norms(self, x, q_lo=2, q_hi=None):
         """(W, q_hi+1) float64; RamanujanPeriods.py:67-86."""
         x, code, W, N, fl, mk = self._prep(x)

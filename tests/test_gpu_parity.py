@@ -249,6 +249,35 @@ def test_best_frequency_matches_reference_golden(eng, golden):
     assert rel_err(pw, g["bf_c1_powers"]) < TOL and rel_err(bs, g["bf_c1_bases"]) < TOL
 
 
+def test_best_frequency_device_variants(eng):
+    """Spectral peak on the device (direct DFT): window sizes other than N, flag combinations, a
+    batch, float32, and the reference's division by zero when the peak is the DC bin."""
+    from pyperiod_amd import Periods
+
+    x = multi_sinusoid_batch(40, 3, 1500)
+    for win in (None, 1500, 2048, 1000, 1499):
+        per, pw, bs, st = eng.best_frequency(x, win, 3)
+        assert not np.asarray(st).any()
+        for w in range(3):
+            rper, rpw, rbs = po.best_frequency(x[w], win, 3)
+            assert np.array_equal(per[w], rper), (win, w)
+            assert rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL, (win, w)
+    for trunc, orth in ((True, False), (False, True), (True, True)):
+        per, pw, bs, st = eng.best_frequency(x[:1], None, 2, trunc, orth)
+        rper, rpw, rbs = po.best_frequency(x[0], None, 2, trunc, orth)
+        assert np.array_equal(per[0], rper) and rel_err(pw[0], rpw) < TOL and rel_err(bs[0], rbs) < TOL
+    per32, pw32, bs32, _ = eng.best_frequency(x.astype(np.float32), None, 2)
+    per64, pw64, _, _ = eng.best_frequency(x, None, 2)
+    assert np.array_equal(per32, per64) and rel_err(pw32, pw64) < 1e-4
+    # a signal riding on a large offset peaks at bin 0: 2 * win / 0 -> OverflowError in the reference
+    with pytest.raises(OverflowError):
+        Periods().best_frequency(x[0] + 50.0, None, 2)
+    with pytest.warns(UserWarning):
+        Periods().best_frequency(x[0], 1000, 1)
+    res = Periods().best_frequency(x, None, 2)  # batched class surface
+    assert res[0].shape == (3, 2) and res[2].shape == (3, 2, 1500)
+
+
 # ------------------------------------------------------------------------------ Ramanujan
 def test_ramanujan_matches_reference_golden(eng, golden):
     from pyperiod_amd import RamanujanPeriods
