@@ -486,6 +486,46 @@ __device__ __forceinline__ void seg_group(typename Win<T, LDS>::ptr ptr, int p, 
   }
 }
 
+// Single-period norm passes over few rows (large p: NR = rows of the segment <= 6, half of all
+// passes of the m_best sweep).  The rows are unrolled at compile time: all NR x C loads are in
+// flight before the one wait, the sums start from row 0 and there is no accumulator
+// initialisation, loop control or remainder handling per group (-15 % on these passes).
+template <typename T, int NR, int C, bool MASK, bool LDS>
+__device__ __forceinline__ void rows_group(typename Win<T, LDS>::ptr ptr, int p, int nvalid, int lane, double& part) {
+  T v[NR][C];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[r][c] = ptr[r * p + 64 * c];
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    double t = (double)v[0][c];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) t += (double)v[r][c];
+    if (MASK) t = (64 * c + lane < nvalid) ? t : 0.0;
+    part = fma(t, t, part);
+  }
+}
+
+template <typename T, int NR, bool LDS>
+__device__ __forceinline__ void rows_segment(typename Win<T, LDS>::ptr base, int p, int len, int lane, double& part) {
+  constexpr int CG = NR <= 4 ? 4 : 2;  // NR x CG loads (<= 16) in flight per wave
+  const int nchunks = (len + 63) >> 6;
+  const int whole = len >> 6;
+  int c0 = 0;
+  for (; c0 + CG <= whole; c0 += CG) rows_group<T, NR, CG, false, LDS>(base + 64 * c0, p, 64 * CG, lane, part);
+  for (; c0 + 1 < nchunks; c0 += 2) {
+    asm volatile("" ::: "memory");
+    rows_group<T, NR, 2, true, LDS>(base + 64 * c0, p, len - 64 * c0, lane, part);
+  }
+  if (c0 < nchunks) {
+    asm volatile("" ::: "memory");
+    rows_group<T, NR, 1, true, LDS>(base + 64 * c0, p, len - 64 * c0, lane, part);
+  }
+}
+
 // Per-lane partials of ||P_q x||^2 for q = p (M >= 1), 2p (M >= 2), 4p (M == 4) -- or of
 // max_s |S_p[s]| (MAXABS, M == 1, row-order sums) -- for a base period p >= 64.
 template <typename T, int M, bool MAXABS, bool LDS>
@@ -526,9 +566,24 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
     const int whole = len >> 6;  // chunks whose 64 residues all belong to the segment
     double sacc[3] = {0.0, 0.0, 0.0};
     double(&part)[3] = (M <= 2) ? sacc : total;
-    for (; c0 + CM <= whole; c0 += CM)
-      seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
-    if (CM == 4) {
+    bool done = false;
+    if (M == 1 && !MAXABS) {  // few rows: compile-time row count (norm passes only: the max|S| kernels spill)
+      done = true;
+      switch (nrows) {
+        case 1: rows_segment<T, 1, LDS>(base, p, len, lane, part[0]); break;
+        case 2: rows_segment<T, 2, LDS>(base, p, len, lane, part[0]); break;
+        case 3: rows_segment<T, 3, LDS>(base, p, len, lane, part[0]); break;
+        case 4: rows_segment<T, 4, LDS>(base, p, len, lane, part[0]); break;
+        case 5: rows_segment<T, 5, LDS>(base, p, len, lane, part[0]); break;
+        case 6: rows_segment<T, 6, LDS>(base, p, len, lane, part[0]); break;
+        default: done = false; break;
+      }
+    }
+    if (done) {
+      // whole segment folded by the unrolled-rows path
+    } else if (CM == 4) {
+      for (; c0 + CM <= whole; c0 += CM)
+        seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
       switch (nchunks - c0) {
         case 4: seg_group<T, M, U, 4, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         case 3: seg_group<T, M, U, 3, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
@@ -537,6 +592,8 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
         default: break;
       }
     } else {
+      for (; c0 + CM <= whole; c0 += CM)
+        seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
       switch (nchunks - c0) {
         case 2: seg_group<T, M, U, 2, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         case 1: seg_group<T, M, U, 1, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
