@@ -246,9 +246,9 @@ __device__ __forceinline__ double wave_partial_small_maxabs(const T* __restrict_
 }
 
 // p < 64: G = 64/p row groups fill the wavefront (lane = g p + j reads x[lane + r G p],
-// contiguous), the G partial sums of a residue are combined with shuffles.  Every lane returns
-// S_p[lane mod p].  Summation order differs from the reference's; only used where the
-// reference's own order is undefined.
+// contiguous), the G partial sums of a residue are combined with a shuffle tree.  Lane j < p
+// returns S_p[j] (the other lanes hold partial sums).  Summation order differs from the
+// reference's; only used where the reference's own order is undefined.
 template <typename T>
 __device__ __forceinline__ double wave_fold_small(const T* __restrict__ xs, int N, int p, int lane) {
   const int G = 64 / p;
@@ -273,10 +273,16 @@ __device__ __forceinline__ double wave_fold_small(const T* __restrict__ xs, int 
   const bool tail = on && (full * L + lane < N);
   const T tv = xs[tail ? full * L + lane : 0];
   double part = s0 + s1 + (tail ? (double)tv : 0.0);
-  part = on ? part : 0.0;
-  const int j = lane % p;
-  double tot = 0.0;
-  for (int gi = 0; gi < G; ++gi) tot += __shfl(part, j + gi * p, kWave);
+  double tot = on ? part : 0.0;
+  // binary tree over the row groups: lane l adds lane l + s p for s = G'/2, ..., 1 (G' = G rounded up
+  // to a power of two); after log2(G') steps the lanes below p hold the totals
+  int s = 1;
+  while (s < G) s <<= 1;
+  for (s >>= 1; s >= 1; s >>= 1) {
+    const int src = lane + s * p;
+    const double o = __shfl(tot, src & (kWave - 1), kWave);
+    tot += (src < L) ? o : 0.0;
+  }
   return tot;
 }
 

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x
         default: break;
       }
     } else {
-      const double tot = wave_fold_small(xs, N, q, lane);  // row-split path, S_q[lane mod q]
+      const double tot = wave_fold_small(xs, N, q, lane);  // row-split path, S_q[lane] in the lanes below q
       if (lane < q) sbuf[lane] = tot;
     }
     wave_sync();
