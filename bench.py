@@ -248,7 +248,7 @@ def main():
                 "parallelism": f"windows sharded over {world} GPU(s), no data-path collective",
             },
             "roofline": {
-                "kernel": "k_mbest_step1<double>",
+                "kernel": "k_mbest_step1<double, true>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
