@@ -116,7 +116,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-root-leg", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
+    ap.add_argument("--root-leg", action="store_true",
+                    help="N > 1: also time the batch-on-rank-0 deployment shape (RCCL scatter -> m_best -> gather), "
+                         "reported separately, never part of `value`")
+    ap.add_argument("--no-root-leg", action="store_true", help=argparse.SUPPRESS)  # accepted, the leg is opt-in now
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -184,7 +187,7 @@ def main():
     # is scattered with RCCL, processed, and the fixed-shape results are gathered back --
     # the "RCCL scatter/gather over xGMI" deployment shape.  Never part of `value`.
     root_leg = None
-    if world > 1 and not args.no_root_leg:
+    if world > 1 and args.root_leg and not args.no_root_leg:
         try:
             from pyperiod_amd.dist import gather_rows, scatter_windows
 
