@@ -159,8 +159,9 @@ int ph_best_correlation(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N,
  * num times: k = argmax |rfft(residual, win_size)| (first maximum, Periods.py:386-389),
  * p = round(2 win_size / k) (:390-391, round-half-even), project, store, subtract (:392-397).
  * The spectrum is a direct real DFT over the first min(N, win_size) samples (any win_size, no FFT
- * library), twiddles from a float64 table; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH
- * (orth tables must cover p <= 2 win_size).  win_size < 1 = N (:381-382).
+ * library; bins spread over the whole GPU, so a single window is fast too), twiddles from a
+ * float64 table; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH (orth tables must cover
+ * p <= 2 win_size).  win_size < 1 = N (:381-382).  Two launches per round; W <= 65535.
  * periods (W, num) uint32; powers (W, num) float64 = norm / ||data|| (:397-399); bases
  * (W, num, N).  status PH_ST_NO_PERIOD: the spectral peak was bin 0 (or the spectrum NaN) at
  * some iteration -- the reference divides by zero there and raises OverflowError; rows from that

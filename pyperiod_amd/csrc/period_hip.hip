@@ -808,14 +808,16 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   if (L < 2 || L > (1 << 24)) return fail(PH_E_ARG, "win_size=%d out of range", L);
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  size_t lds = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
-               carve_bytes(kMaxWaves, 4);
+  size_t lds = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8);  // update kernel
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, true, (size_t)N * sz, W, &gbuf));
   PH_TRY(check_lds(c, lds, N, "ph_best_frequency"));
+  const size_t lds_spec = carve_bytes(N, sz) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+  PH_TRY(check_lds(c, lds_spec, N, "ph_best_frequency"));
+  const int nchunk = (L / 2 + 1 + ph::kBfBlock - 1) / ph::kBfBlock;
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, 2 * L, &tb));
-  if (c->twid_len != L) {  // twiddles in float64, argument reduced exactly: k / L is a fraction of a turn
+  if (c->twid_len != L) {  // twiddles in float64; k / L is an exact fraction of a turn
     std::vector<double> tw(2 * (size_t)L);
     const long double two_pi = 6.283185307179586476925286766559L;
     for (int k = 0; k < L; ++k) {
@@ -837,22 +839,40 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   PH_TRY(st.out(B_OUT1, powers, (size_t)W * num * sizeof(double), &dpow));
   PH_TRY(st.out(B_OUT2, bases, (size_t)W * num * N * sz, &dbases));
   PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
+  // workspace: the residual, per-chunk spectral maxima, ||data||
+  PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * N * sz));
+  PH_TRY(ensure(c, c->buf[B_WS0], (size_t)W * nchunk * sizeof(double) + (size_t)W * sizeof(double)));
+  PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * nchunk * sizeof(int)));
+  void* dres = c->buf[B_GWIN].p;
+  double* dpart = static_cast<double*>(c->buf[B_WS0].p);
+  double* dnrm = dpart + (size_t)W * nchunk;
+  int* dpartk = static_cast<int*>(c->buf[B_WS1].p);
+  PH_HIP(hipMemcpyAsync(dres, dx, (size_t)W * N * sz, hipMemcpyDeviceToDevice, c->stream));
+  PH_HIP(hipMemsetAsync(dstat, 0, (size_t)W * sizeof(int32_t), c->stream));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
-  const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_best_frequency<double>, lds));
-    ProfScope ps_(c, "k_best_frequency");
-    hipLaunchKernelGGL(ph::k_best_frequency<double>, grid, dim3(kBlockWide), lds, c->stream, (const double*)dx, N, L,
-                       num, kflags, tb, (const double2*)c->twid.p, (double*)gbuf, (uint32_t*)dper, (double*)dpow,
-                       (double*)dbases, (int*)dstat);
-  } else {
-    PH_TRY(allow_lds(ph::k_best_frequency<float>, lds));
-    ProfScope ps_(c, "k_best_frequency");
-    hipLaunchKernelGGL(ph::k_best_frequency<float>, grid, dim3(kBlockWide), lds, c->stream, (const float*)dx, N, L,
-                       num, kflags, tb, (const double2*)c->twid.p, (float*)gbuf, (uint32_t*)dper, (double*)dpow,
-                       (float*)dbases, (int*)dstat);
-  }
-  PH_TRY(launch_check("k_best_frequency"));
+  const dim3 grid_s((unsigned)nchunk, (unsigned)W), grid_u((unsigned)W);
+  if (W > 65535) return fail(PH_E_ARG, "ph_best_frequency: W=%lld exceeds 65535 windows per call", (long long)W);
+  PH_TRY(dispatch(dtype, true, [&](auto t, auto) {
+    using T = decltype(t);
+    PH_TRY(allow_lds(ph::k_bf_spectrum<T>, lds_spec));
+    PH_TRY(allow_lds(ph::k_bf_update<T>, lds));
+    for (int it = 0; it < num; ++it) {
+      {
+        ProfScope ps_(c, "k_bf_spectrum");
+        hipLaunchKernelGGL(ph::k_bf_spectrum<T>, grid_s, dim3(ph::kBfBlock), lds_spec, c->stream, (const T*)dres, N, L,
+                           (const double2*)c->twid.p, (const int*)dstat, dpart, dpartk);
+      }
+      PH_TRY(launch_check("k_bf_spectrum"));
+      {
+        ProfScope ps_(c, "k_bf_update");
+        hipLaunchKernelGGL(ph::k_bf_update<T>, grid_u, dim3(kBlockWide), lds, c->stream, (T*)dres, N, L, num, it,
+                           kflags, tb, (T*)gbuf, nchunk, (const double*)dpart, (const int*)dpartk, dnrm,
+                           (uint32_t*)dper, (double*)dpow, (T*)dbases, (int*)dstat);
+      }
+      PH_TRY(launch_check("k_bf_update"));
+    }
+    return (int)PH_OK;
+  }));
   return st.finish();
 }
 

@@ -733,104 +733,138 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 }
 
 // ======================================================================================
-// Periods.best_frequency  (Periods.py:351-398).  One workgroup per window.
-//   spectrum: thread per rfft bin k, X[k] = sum_n x[n] (cos - i sin)(2 pi k n / L) with the phase
-//   index k n mod L kept incrementally and the twiddles read from a float64 table (L2-resident);
-//   argmax |X[k]|^2, first maximum.  Then p = rint(2 L / k), project (all flag combinations),
-//   store, subtract.
+// Periods.best_frequency  (Periods.py:351-398).  Two launches per round:
+//   k_bf_spectrum: grid (bin chunks, W).  The residual is staged in LDS; thread per rfft bin k,
+//     X[k] = sum_n x[n] (cos - i sin)(2 pi k n / L) with the phase index k n mod L kept
+//     incrementally and the twiddles read from a float64 table (L2-resident); every workgroup
+//     leaves its best (|X|^2, k), first maximum.  A single window still fills the chip.
+//   k_bf_update: one workgroup per window: argmax over the chunks, p = rint(2 L / k), project
+//     (all flag combinations), store, subtract, residual back to the HBM workspace.
 // ======================================================================================
+constexpr int kBfBlock = 256;
+
 template <typename T>
-__global__ __launch_bounds__(kBlockWide) void k_best_frequency(const T* __restrict__ x, int N, int L, int num,
-                                                               unsigned flags, Tables tb,
-                                                               const double2* __restrict__ tw, T* __restrict__ gbuf,
-                                                               uint32_t* __restrict__ periods_out,
-                                                               double* __restrict__ powers_out,
-                                                               T* __restrict__ bases_out,
-                                                               int* __restrict__ status_out) {
+__global__ __launch_bounds__(kBfBlock) void k_bf_spectrum(const T* __restrict__ res, int N, int L,
+                                                          const double2* __restrict__ tw,
+                                                          const int* __restrict__ status,
+                                                          double* __restrict__ part_m2, int* __restrict__ part_k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  T* xs = cv.take<T>(N);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  const int64_t w = blockIdx.y;
+  const int chunk = blockIdx.x, nchunk = gridDim.x;
+  if (status[w] != 0) return;  // the reference has raised for this window already
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int M = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
+  load_window(res + w * (int64_t)N, xs, N);
+  __syncthreads();
+  double best = -1.0;
+  int bestk = 0;  // bin + 1; 0 = none
+  const int k = chunk * (int)blockDim.x + tid;
+  if (k <= L / 2) {
+    double re = 0.0, im = 0.0;
+    int idx = 0;
+    for (int n = 0; n < M; ++n) {
+      const double xv = (double)xs[n];
+      const double2 cs = tw[idx];
+      re = fma(xv, cs.x, re);
+      im = fma(xv, cs.y, im);
+      idx += k;
+      if (idx >= L) idx -= L;
+    }
+    const double m2 = re * re + im * im;
+    if (m2 > best) {  // false for NaN
+      best = m2;
+      bestk = k + 1;
+    }
+  }
+  wave_argmax(best, bestk);
+  if (lane == 0) {
+    wbest[wv] = best;
+    wbestp[wv] = bestk;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    best = -1.0;
+    bestk = 0;
+    for (int i = 0; i < nw; ++i)
+      if (wbestp[i] != 0 && (bestk == 0 || wbest[i] > best || (wbest[i] == best && wbestp[i] < bestk))) {
+        best = wbest[i];
+        bestk = wbestp[i];
+      }
+    part_m2[w * nchunk + chunk] = best;
+    part_k[w * nchunk + chunk] = bestk;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, int N, int L, int num, int it,
+                                                          unsigned flags, Tables tb, T* __restrict__ gbuf, int nchunk,
+                                                          const double* __restrict__ part_m2,
+                                                          const int* __restrict__ part_k, double* __restrict__ dnorm,
+                                                          uint32_t* __restrict__ periods_out,
+                                                          double* __restrict__ powers_out, T* __restrict__ bases_out,
+                                                          int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* work = cv.take<T>(N);
   T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
-  double* wbest = cv.take<double>(kMaxWaves);
-  int* wbestp = cv.take<int>(kMaxWaves);
-
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = blockDim.x >> 6;
-  T* bases = bases_out + w * (int64_t)num * N;
-  load_window(x + w * (int64_t)N, work, N);
-  __syncthreads();
-  const double data_norm = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
-  const int M = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
-  int status = 0, done = 0;
-  for (int it = 0; it < num; ++it) {
-    // ---- spectral peak
+  T* brow = bases_out + (w * num + it) * (int64_t)N;
+  bool dead = status[w] != 0;
+  int p = 0;
+  if (!dead) {
     double best = -1.0;
-    int bestk = 0;  // bin + 1; 0 = none
-    for (int k = tid; k <= L / 2; k += blockDim.x) {
-      double re = 0.0, im = 0.0;
-      int idx = 0;
-      for (int n = 0; n < M; ++n) {
-        const double xv = (double)work[n];
-        const double2 cs = tw[idx];
-        re = fma(xv, cs.x, re);
-        im = fma(xv, cs.y, im);
-        idx += k;
-        if (idx >= L) idx -= L;
-      }
-      const double m2 = re * re + im * im;
-      if (m2 > best) {  // ascending k per thread: strict '>' keeps the first maximum
-        best = m2;
-        bestk = k + 1;
-      }
-    }
-    wave_argmax(best, bestk);
-    if (lane == 0) {
-      wbest[wv] = best;
-      wbestp[wv] = bestk;
-    }
-    __syncthreads();
-    best = -1.0;
-    bestk = 0;
-    for (int i = 0; i < nw; ++i) {
-      const double v = wbest[i];
-      const int kk = wbestp[i];
-      if (kk != 0 && (bestk == 0 || v > best || (v == best && kk < bestk))) {
+    int bestk = 0;
+    for (int c = 0; c < nchunk; ++c) {  // chunks in ascending bin order: strict '>' keeps the first maximum
+      const double v = part_m2[w * nchunk + c];
+      const int kk = part_k[w * nchunk + c];
+      if (kk != 0 && (bestk == 0 || v > best)) {
         best = v;
         bestk = kk;
       }
     }
-    __syncthreads();
     if (bestk <= 1) {  // bin 0 (or nothing comparable): 2 L / 0 in the reference
-      status = 1;
-      break;
+      dead = true;
+      __syncthreads();  // every thread has read status[w]
+      if (tid == 0) status[w] = 1;
+    } else {
+      p = (int)rint(2.0 * (double)L / (double)(bestk - 1));
     }
-    const int p = (int)rint(2.0 * (double)L / (double)(bestk - 1));
-    // ---- project, store, subtract (Periods.py:392-397)
-    project_lds(work, buf, N, p, flags, tb);
-    const double nrm = periodic_norm_from_sq(block_sumsq(buf, N, red), N, 0);
-    T* brow = bases + (int64_t)it * N;
-    for (int n = tid; n < N; n += blockDim.x) {
-      const T b = buf[n];
-      brow[n] = b;
-      work[n] -= b;
-    }
+  }
+  if (dead) {  // rows from the failing round on stay zero
+    for (int n = tid; n < N; n += blockDim.x) brow[n] = T(0);
     if (tid == 0) {
-      periods_out[w * num + it] = (uint32_t)p;
-      powers_out[w * num + it] = nrm / data_norm;
+      periods_out[w * num + it] = 0u;
+      powers_out[w * num + it] = 0.0;
     }
-    done = it + 1;
-    __syncthreads();
+    return;
   }
-  for (int64_t n = (int64_t)done * N + tid; n < (int64_t)num * N; n += blockDim.x) bases[n] = T(0);
-  for (int k = done + tid; k < num; k += blockDim.x) {
-    periods_out[w * num + k] = 0u;
-    powers_out[w * num + k] = 0.0;
+  load_window(res + w * (int64_t)N, work, N);
+  __syncthreads();
+  double dn;
+  if (it == 0) {
+    dn = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
+    if (tid == 0) dnorm[w] = dn;
+  } else {
+    dn = dnorm[w];
   }
-  if (tid == 0) status_out[w] = status;
+  project_lds(work, buf, N, p, flags, tb);
+  const double nrm = periodic_norm_from_sq(block_sumsq(buf, N, red), N, 0);
+  for (int n = tid; n < N; n += blockDim.x) {
+    const T b = buf[n];
+    brow[n] = b;
+    res[w * (int64_t)N + n] = work[n] - b;
+  }
+  if (tid == 0) {
+    periods_out[w * num + it] = (uint32_t)p;
+    powers_out[w * num + it] = nrm / dn;
+  }
 }
 
 // ======================================================================================
