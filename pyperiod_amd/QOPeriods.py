@@ -184,7 +184,9 @@ class QOPeriods(Periods):
 
     def _find_periods_device(self, eng, data, N, num, thresh, min_length, max_length):
         """Assemble the reference's return value from the device loop's compact outputs."""
-        kcap = 512
+        # a block adds at most max_length rows: start with room for all of them when that fits
+        bound = int(num) * int(max_length if max_length is not None else N // 3)
+        kcap = min(2048, max(64, -(-bound // 64) * 64)) if bound <= 2048 else 512
         while True:
             per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(
                 data[None, :], num, thresh, min_length, max_length, kcap

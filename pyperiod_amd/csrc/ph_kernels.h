@@ -1236,7 +1236,18 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
           const bool is_rhs = rr == nr - 1;
           const double* src = is_rhs ? yv + t0 : L + (int64_t)t0 * kcap + J + rr;
           const int64_t stride = is_rhs ? 1 : kcap;
-          for (int tt = 0; tt < tn; ++tt) {
+          int tt = 0;
+          for (; tt + 8 <= tn; tt += 8) {  // eight independent HBM loads in flight, then their fma (16 was slower)
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = src[(tt + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+              for (int cc = 0; cc < kQoPanelMax; ++cc)
+                acc[cc] = fma(a[u], tile[(tt + u) * kQoPanelMax + cc], acc[cc]);
+          }
+          for (; tt < tn; ++tt) {
             const double a = src[tt * stride];
 #pragma unroll
             for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = fma(a, tile[tt * kQoPanelMax + cc], acc[cc]);
