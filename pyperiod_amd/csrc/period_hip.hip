@@ -147,6 +147,23 @@ int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n
     for (int d = 1; d <= m; d *= 2) covered[(size_t)d * p] = 1;
     host.push_back(ph::PassPlan{p, m});
   }
+  // Interleave the pass types evenly (entry i of a type with n entries gets the key (i + 0.5) / n):
+  // the waves of a CU walk the plan in step, and a mix of LDS-heavy single passes and VALU-heavy
+  // multi-class passes overlaps better than a phase of each.
+  if (!std::getenv("PH_PLAN_SORTED")) {
+    int count[5] = {0, 0, 0, 0, 0}, seen[5] = {0, 0, 0, 0, 0};
+    for (const auto& e : host) count[e.m] += 1;
+    std::vector<std::pair<double, size_t>> key(host.size());
+    for (size_t i = 0; i < host.size(); ++i) {
+      const int m = host[i].m;
+      key[i] = {(seen[m] + 0.5) / count[m], i};
+      seen[m] += 1;
+    }
+    std::stable_sort(key.begin(), key.end());
+    std::vector<ph::PassPlan> mixed(host.size());
+    for (size_t i = 0; i < host.size(); ++i) mixed[i] = host[key[i].second];
+    host.swap(mixed);
+  }
   if (const char* only = std::getenv("PH_PLAN_ONLY_M")) {  // profiling aid: keep one pass type (results incomplete)
     const int want = std::atoi(only);
     std::vector<ph::PassPlan> kept;
