@@ -823,6 +823,7 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   if (num < 1) return fail(PH_E_ARG, "num=%d must be >= 1", num);
   const int L = win_size < 1 ? N : win_size;  // Periods.py:381-382
   if (L < 2 || L > (1 << 24)) return fail(PH_E_ARG, "win_size=%d out of range", L);
+  if (W > 65535) return fail(PH_E_ARG, "ph_best_frequency: W=%lld exceeds 65535 windows per call", (long long)W);
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   size_t lds = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8);  // update kernel
@@ -868,7 +869,6 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   PH_HIP(hipMemsetAsync(dstat, 0, (size_t)W * sizeof(int32_t), c->stream));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid_s((unsigned)nchunk, (unsigned)W), grid_u((unsigned)W);
-  if (W > 65535) return fail(PH_E_ARG, "ph_best_frequency: W=%lld exceeds 65535 windows per call", (long long)W);
   PH_TRY(dispatch(dtype, true, [&](auto t, auto) {
     using T = decltype(t);
     PH_TRY(allow_lds(ph::k_bf_spectrum<T>, lds_spec));
