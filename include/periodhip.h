@@ -96,8 +96,8 @@ const char* ph_profile_name(ph_ctx* ctx, int i);
 int ph_device_info(ph_ctx* ctx, int* num_cu, int* lds_bytes);
 /* Largest N for which a window of `dtype` stays LDS-resident (the fast path).  Longer windows are
  * accepted by project/sweep/m_best/small_to_large/best_correlation/ramanujan_norms -- the window
- * then lives in an HBM workspace -- and rejected (PH_E_ARG) by qo_find_periods, fold_sums and
- * orth_powers.  `flags` is ignored. */
+ * then lives in an HBM workspace -- and rejected (PH_E_ARG) by best_frequency, qo_find_periods,
+ * fold_sums and orth_powers.  `flags` is ignored. */
 int ph_max_window(ph_ctx* ctx, int dtype, unsigned flags, int* max_n);
 
 /* ---- Periods.periodic_norm over a batch (Periods.py:221-241) ---------------------------
