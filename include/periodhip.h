@@ -79,7 +79,11 @@ int ph_device_count(int* count);
 int ph_create(int device, ph_ctx** out);
 int ph_destroy(ph_ctx* ctx);
 /* Borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL
- * restores the context's own stream. */
+ * restores the context's own (non-blocking) stream.  The device's default stream has the
+ * handle 0, which cannot be told from NULL: pass PH_STREAM_DEFAULT for it -- work the caller
+ * enqueued on the default stream (torch's current stream unless changed) is then ordered with
+ * the library's kernels. */
+#define PH_STREAM_DEFAULT ((void*)1)
 int ph_set_stream(ph_ctx* ctx, void* hip_stream);
 int ph_sync(ph_ctx* ctx);
 /* HIP-event timer on the context's stream (the stream the kernels run on). */

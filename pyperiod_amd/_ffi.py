@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("PYPERIOD_AMD_LIB") or os.path.join(_HERE, LIB_NAME)  
 PH_OK, PH_E_ARG, PH_E_HIP, PH_E_NOMEM, PH_E_CAP, PH_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 PH_F64, PH_F32 = 0, 1
 PH_FLAG_TRUNC, PH_FLAG_ORTH, PH_FLAG_SINGLE, PH_FLAG_DEVICE = 1, 2, 4, 8
+PH_STREAM_DEFAULT = 1  # ph_set_stream handle of the device default stream (its real handle, 0, means "own stream")
 PH_SWEEP_NORM, PH_SWEEP_NORM_GAMMA, PH_SWEEP_MAXABS = 0, 1, 2
 PH_ST_OK, PH_ST_NO_PERIOD, PH_ST_ITER_CAP, PH_ST_CAP = 0, 1, 2, 3
 

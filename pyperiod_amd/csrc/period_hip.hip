@@ -475,7 +475,10 @@ int ph_destroy(ph_ctx* c) {
 int ph_set_stream(ph_ctx* c, void* hip_stream) {
   if (!c) return fail(PH_E_ARG, "ctx is NULL");
   PH_HIP(hipStreamSynchronize(c->stream));
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (hip_stream == PH_STREAM_DEFAULT)
+    c->stream = nullptr;  // the legacy default stream
+  else
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
   return PH_OK;
 }
 

@@ -112,7 +112,8 @@ class PeriodEngine:
             code = {torch.float64: _ffi.PH_F64, torch.float32: _ffi.PH_F32}.get(x.dtype)
             if code is None:
                 raise TypeError(f"unsupported dtype {x.dtype}")
-            stream = torch.cuda.current_stream(x.device).cuda_stream
+            # torch's default stream has the handle 0 (== NULL, "own stream" in the C ABI)
+            stream = torch.cuda.current_stream(x.device).cuda_stream or _ffi.PH_STREAM_DEFAULT
             if stream != self._bound_stream:
                 _ffi.check(self._lib.ph_set_stream(self._ctx, C.c_void_p(stream)))
                 self._bound_stream = stream

@@ -64,6 +64,29 @@ def test_config4_shard_small_to_large(eng, golden):
         assert list(per[w, : counts[w]]) == rper and rel_err(pw[w, : counts[w]], rpw) < TOL
 
 
+def test_config4_full_batch_device_resident(eng):
+    """BASELINE config 4 in one call: 65 536 windows x N=4096 resident in HBM (2 GiB), periods only.
+    Index widths, grid size and the per-window independence at full scale."""
+    import torch
+
+    base = multi_sinusoid_batch(0, 256, 4096)
+    x = torch.from_numpy(base).cuda().repeat(256, 1)
+    counts, per, pw, bs, st = eng.small_to_large(x, 0.05, None, False, False, cap=24, want_bases=False)
+    counts, per, pw = counts.cpu().numpy(), per.cpu().numpy(), pw.cpu().numpy()
+    assert int(st.abs().max()) == 0 and counts.shape == (65536,)
+    # every copy of a window gives the same answer, and it is the oracle's
+    assert np.array_equal(counts.reshape(256, 256), np.broadcast_to(counts[:256], (256, 256)))
+    assert np.array_equal(per.reshape(256, 256, -1), np.broadcast_to(per[:256], (256, 256, per.shape[1])))
+    for w in (5, 200):
+        rper, rpw, _ = po.small_to_large(base[w], 0.05)
+        for k in (w, w + 256 * 255):
+            assert list(per[k, : counts[k]]) == rper and rel_err(pw[k, : counts[k]], rpw) < TOL
+    out = eng.m_best(x[:16384].contiguous(), 10)
+    pp = out[0].cpu().numpy().view(np.uint32)
+    assert np.array_equal(pp.reshape(64, 256, 10), np.broadcast_to(pp[:256], (64, 256, 10)))
+    assert np.array_equal(pp[7 + 256 * 63], po.m_best(base[7], 10)[0])
+
+
 def test_config3_ramanujan_batch(eng, golden):
     """Config 3 shape: N=8192, Pmax=512, a batch of windows in one launch."""
     W, n, pmax = 256, 8192, 512
