@@ -1,0 +1,85 @@
+"""Extended differential fuzz against the oracle (not collected by pytest): many more random shapes than
+tests/test_gpu_random.py, different seeds.  Prints mismatches and a summary."""
+import os, sys, time, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+warnings.simplefilter("ignore")
+import numpy as np
+from oracle import period_oracle as po
+from pyperiod_amd import default_engine, _ffi
+from pyperiod_amd.synth import multi_sinusoid_batch
+eng = default_engine()
+TOL = 1e-10
+def rel(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    d = np.abs(a - b).max() if a.size else 0.0
+    return d / max(1e-300, np.abs(b).max() if b.size else 1.0)
+def windows(rng, w, n):
+    k = rng.integers(0, 4)
+    if k == 0 and n >= 88: return multi_sinusoid_batch(int(rng.integers(0, 10000)), w, n)
+    if k == 1: return rng.standard_normal((w, n))
+    if k == 2: return np.round(rng.standard_normal((w, n)) * 4) / 4      # many exact ties
+    t = np.arange(n)
+    return np.stack([np.sin(2*np.pi*t/rng.integers(3, max(4, n//4))) + 0.05*rng.standard_normal(n) for _ in range(w)])
+bad = 0; t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 120
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+rng = np.random.default_rng(seed); trials = 0
+while time.time() < t_end:
+    trials += 1
+    n = int(rng.integers(8, 6000)); w = int(rng.integers(1, 3)); x = windows(rng, w, n)
+    which = rng.integers(0, 6)
+    try:
+        if which == 0:
+            lo = int(rng.integers(1, max(2, min(n, 300)))); hi = int(rng.integers(lo, max(lo+1, min(n, 2500)))); mode = int(rng.integers(0, 3))
+            got = eng.sweep(x, lo, hi, mode)
+            for i in range(w):
+                want = po.sweep_maxabs(x[i], lo, hi) if mode == 2 else po.sweep_norms(x[i], lo, hi, gamma=(mode == 1))
+                s = slice(1, None) if lo == 1 else slice(None)
+                if rel(got[i][s], want[s]) > TOL: bad += 1; print("SWEEP", n, lo, hi, mode, rel(got[i][s], want[s]))
+        elif which == 1 and n >= 12:
+            num = int(rng.integers(1, 8)); gamma = bool(rng.integers(0, 2)); ml = int(rng.integers(3, max(4, n//2)))
+            per, pw, bs, st = eng.m_best(x, num, ml, 2, gamma)
+            for i in range(w):
+                try: r = po.m_best(x[i], num, ml, 2, gamma)
+                except Exception: r = None
+                if r is None:
+                    if st[i] == 0: bad += 1; print("MBEST status", n, num, ml, gamma)
+                    continue
+                if st[i] != 0 or not np.array_equal(per[i], r[0]) or rel(pw[i], r[1]) > TOL or rel(bs[i], r[2]) > TOL:
+                    bad += 1; print("MBEST", n, num, ml, gamma, st[i], per[i], r[0])
+        elif which == 2 and n >= 8:
+            th = float(rng.choice([0.02, 0.05, 0.1, 0.3])); npd = int(rng.integers(2, max(3, n//2)))
+            c, per, pw, bs, st = eng.small_to_large(x, th, npd)
+            for i in range(w):
+                r = po.small_to_large(x[i], th, npd)
+                if list(per[i, :c[i]]) != r[0] or (len(r[1]) and rel(pw[i, :c[i]], r[1]) > TOL):
+                    bad += 1; print("S2L", n, th, npd, list(per[i, :c[i]]), r[0])
+        elif which == 3 and n >= 12:
+            num = int(rng.integers(1, 4)); ml = int(rng.integers(4, max(5, n//3)))
+            per, nr, bs, st = eng.best_correlation(x, num, ml)
+            for i in range(w):
+                r = po.best_correlation(x[i], num, ml)
+                if not np.array_equal(per[i], r[0]) or rel(nr[i], r[1]) > TOL or rel(bs[i], r[2]) > TOL:
+                    bad += 1; print("BC", n, num, ml, per[i], r[0])
+        elif which == 4:
+            pl = [int(v) for v in rng.integers(1, max(2, min(n, 3000)), size=int(rng.integers(1, 6)))]
+            trunc = bool(rng.integers(0, 2)); orth = bool(rng.integers(0, 2))
+            got = eng.project_batch(x, pl, trunc, orth)
+            for i in range(w):
+                for k, p in enumerate(pl):
+                    if p == 1: continue
+                    want = po.project(x[i], p, trunc, orth)
+                    if not np.array_equal(got[i, k], want, equal_nan=True): bad += 1; print("PROJ", n, p, trunc, orth)
+        elif which == 5 and n >= 64:
+            win = int(rng.choice([n, n, n + int(rng.integers(1, 100)), max(8, n - int(rng.integers(1, 50)))]))
+            per, pw, bs, st = eng.best_frequency(x, win, 2)
+            for i in range(w):
+                try: r = po.best_frequency(x[i], win, 2)
+                except Exception: r = None
+                if r is None:
+                    if st[i] == 0: bad += 1; print("BF status", n, win)
+                    continue
+                if st[i] != 0 or not np.array_equal(per[i], r[0]) or rel(pw[i], r[1]) > 1e-9:
+                    bad += 1; print("BF", n, win, st[i], per[i], r[0], rel(pw[i], r[1]))
+    except Exception as exc:
+        bad += 1; print("EXC", which, n, repr(exc)[:200])
+print("trials", trials, "mismatches", bad)
