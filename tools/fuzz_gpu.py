@@ -26,7 +26,7 @@ rng = np.random.default_rng(seed); trials = 0
 while time.time() < t_end:
     trials += 1
     n = int(rng.integers(8, 6000)); w = int(rng.integers(1, 3)); x = windows(rng, w, n)
-    which = rng.integers(0, 10)
+    which = rng.integers(0, 13)
     try:
         if which == 0:
             lo = int(rng.integers(1, max(2, min(n, 300)))); hi = int(rng.integers(lo, max(lo+1, min(n, 2500)))); mode = int(rng.integers(0, 3))
@@ -116,6 +116,31 @@ while time.time() < t_end:
                 want = po.sweep_norms(x[i], 2, hi, gamma=gamma, trunc=trunc, orth=orth)
                 m = np.isfinite(want)
                 if rel(got[i][m], want[m]) > TOL: bad += 1; print("FSWEEP", n, hi, trunc, orth, gamma, rel(got[i][m], want[m]))
+        elif which == 10 and 24 <= n <= 1500:
+            trunc = bool(rng.integers(0, 2)); orth = not trunc or bool(rng.integers(0, 2))
+            num = int(rng.integers(1, 4)); ml = int(rng.integers(4, max(5, min(n // 3, 40)))); gamma = bool(rng.integers(0, 2))
+            per, pw, bs, st = eng.m_best(x, num, ml, 2, gamma, trunc, orth)
+            for i in range(w):
+                try: r = po.m_best(x[i], num, ml, 2, gamma, trunc, orth)
+                except Exception: r = None
+                if r is None or np.min(np.abs(r[1])) < 1e-10 * np.max(np.abs(r[1])) or not np.all(np.isfinite(r[1])): continue
+                if st[i] != 0 or not np.array_equal(per[i], r[0]) or rel(pw[i], r[1]) > TOL:
+                    bad += 1; print("FMBEST", n, num, ml, gamma, trunc, orth, st[i], per[i], r[0])
+        elif which == 11 and 24 <= n <= 1500:
+            trunc = bool(rng.integers(0, 2)); orth = not trunc or bool(rng.integers(0, 2))
+            th = float(rng.choice([0.05, 0.1, 0.3])); npd = int(rng.integers(2, max(3, min(n // 2, 60))))
+            c, per, pw, bs, st = eng.small_to_large(x, th, npd, trunc, orth)
+            for i in range(w):
+                r = po.small_to_large(x[i], th, npd, trunc, orth)
+                if list(per[i, :c[i]]) != r[0]: bad += 1; print("FS2L", n, th, npd, trunc, orth, list(per[i, :c[i]]), r[0])
+        elif which == 12 and trials % 40 == 0:
+            nl = int(rng.integers(20000, 36000)); xl = multi_sinusoid_batch(int(rng.integers(0, 500)), 1, nl)
+            hi = int(rng.integers(70, 400))
+            got = eng.sweep(xl, 2, hi, 0)
+            if rel(got[0], po.sweep_norms(xl[0], 2, hi)) > TOL: bad += 1; print("LSWEEP", nl, hi)
+            per, pw, bs, st = eng.m_best(xl, 2, hi)
+            r = po.m_best(xl[0], 2, hi)
+            if not np.array_equal(per[0], r[0]) or rel(pw[0], r[1]) > TOL: bad += 1; print("LMBEST", nl, hi, per[0], r[0])
     except Exception as exc:
         bad += 1; print("EXC", which, n, repr(exc)[:200])
 print("trials", trials, "mismatches", bad)
