@@ -290,12 +290,15 @@ class PeriodEngine:
         bases = mk.empty((W, num, N), self._np_dtype(code))
         status = mk.empty((W,), np.int32)
         with self._lock:
-            _ffi.check(
-                self._lib.ph_best_frequency(
-                    self._ctx, mk.addr(x), code, W, N, win_size, num, keep[2], keep[3], keep[4],
-                    fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status),
+            for w0 in range(0, W, 65535):  # the spectrum kernel's grid.y holds the window index
+                w1 = min(W, w0 + 65535)
+                _ffi.check(
+                    self._lib.ph_best_frequency(
+                        self._ctx, mk.addr(x[w0:w1]), code, w1 - w0, N, win_size, num, keep[2], keep[3], keep[4],
+                        fl | self._flags(trunc, orth), mk.addr(periods[w0:w1]), mk.addr(powers[w0:w1]),
+                        mk.addr(bases[w0:w1]), mk.addr(status[w0:w1]),
+                    )
                 )
-            )
         return periods, powers, bases, status
 
     def ramanujan_norms(self, x, q_lo=2, q_hi=None):
