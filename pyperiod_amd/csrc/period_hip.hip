@@ -73,7 +73,7 @@ struct ph_ctx {
   DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
   int twid_len = -1;
   DevBuf plan;  // pass plan of the norm sweeps, cached for the last (p_lo, p_hi)
-  int plan_lo = -1, plan_hi = -1, plan_n = 0;
+  int plan_lo = -1, plan_hi = -1, plan_n = 0, plan_m = -1;
   int plan_max_m = 4;  // largest row-class count a pass may use (PH_PLAN_MAX_M overrides: 1, 2 or 4)
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   // optional per-kernel HIP-event timing (ph_profile_*)
@@ -128,8 +128,9 @@ size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
 // Pass plan of a norm sweep over [p_lo, p_hi]: every period is produced exactly once, either
 // by its own pass or as 2p / 4p of a smaller base period (see PassPlan in ph_device.h).
 // Periods below 64 use the row-split path one at a time (m = 0).
-int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass) {
-  if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi) {
+int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4) {
+  max_m = std::min(max_m, c->plan_max_m);
+  if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi && c->plan_m == max_m) {
     *out = static_cast<const ph::PassPlan*>(c->plan.p);
     *n_pass = c->plan_n;
     return PH_OK;
@@ -143,7 +144,7 @@ int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n
     }
     if (covered[p]) continue;
     int m = (4LL * p <= p_hi) ? 4 : (2LL * p <= p_hi) ? 2 : 1;
-    m = std::min(m, c->plan_max_m);
+    m = std::min(m, max_m);
     for (int d = 1; d <= m; d *= 2) covered[(size_t)d * p] = 1;
     host.push_back(ph::PassPlan{p, m});
   }
@@ -179,6 +180,7 @@ int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n
   PH_HIP(hipStreamSynchronize(c->stream));
   c->plan_lo = p_lo;
   c->plan_hi = p_hi;
+  c->plan_m = max_m;
   c->plan_n = (int)host.size();
   *out = static_cast<const ph::PassPlan*>(c->plan.p);
   *n_pass = c->plan_n;
@@ -911,6 +913,11 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, q_hi, &geom));
+  // pass plan: multi-class passes need the whole base in registers (two-class bases <= 256,
+  // four-class bases <= 128) and rows past the window inside the zero pad (base <= 256)
+  const ph::PassPlan* plan = nullptr;
+  int n_pass = 0;
+  if (q_lo <= q_hi) PH_TRY(prepare_plan(c, q_lo, q_hi, &plan, &n_pass, q_hi <= 512 ? 4 : 1));
   // integer tables: Euler phi and, for every q, q / r for each prime r | q
   std::vector<int32_t> phi(q_hi + 1), off(q_hi + 2, 0), dd;
   {
@@ -949,8 +956,8 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
       auto kernel = ph::k_ramanujan<T, decltype(lw)::value>;
       PH_TRY(allow_lds(kernel, lds));
       ProfScope ps_(c, "k_ramanujan");
-      hipLaunchKernelGGL(kernel, grid, dim3(ph::kRamBlock), lds, c->stream, (const T*)dx, N, q_lo, q_hi, geom, d_off,
-                         d_d, d_phi, (T*)gwin, (double*)dout);
+      hipLaunchKernelGGL(kernel, grid, dim3(ph::kRamBlock), lds, c->stream, (const T*)dx, N, q_lo, q_hi, geom, plan,
+                         n_pass, d_off, d_d, d_phi, (T*)gwin, (double*)dout);
       return (int)PH_OK;
     }));
     PH_TRY(launch_check("k_ramanujan"));

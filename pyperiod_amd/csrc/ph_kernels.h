@@ -896,9 +896,39 @@ __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p
   }
 }
 
+// Class sums of one pass over the window at base period b with M row classes (row r belongs to
+// class r mod M): a[u][c] = sum over rows r = u (mod M) of x[r b + 64 c + lane], for all C chunks
+// of the base at once (b <= 64 C).  Rows past the last one and the part of the last row past N
+// read the zeroed pad behind the window (b <= 256 here, so both stay inside it).
+template <typename T, int M, int C, bool LW>
+__device__ __forceinline__ void ram_fold_classes(const T* __restrict__ xs, int N, int b, int rows, int lane,
+                                                 double (&a)[M][C]) {
+  const typename Win<T, LW>::ptr ptr = Win<T, LW>::cast(xs) + lane;
+#pragma unroll
+  for (int u = 0; u < M; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) a[u][c] = 0.0;
+  for (int r = 0; r < rows; r += M) {
+    T v[M][C];
+#pragma unroll
+    for (int u = 0; u < M; ++u) {
+      const int off = (r + u < rows) ? (r + u) * b : N;  // wave-uniform; N = first pad element
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[off + 64 * c];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u][c] += (double)v[u][c];
+  }
+}
+
 template <typename T, bool LW>
 __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x, int N, int q_lo, int q_hi,
                                                          const PGeom* __restrict__ geom,
+                                                         const PassPlan* __restrict__ plan, int n_pass,
                                                          const int* __restrict__ pr_off,
                                                          const int* __restrict__ pr_d,
                                                          const int* __restrict__ totient, T* gwin,
@@ -921,25 +951,10 @@ __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-
-  for (int q = q_lo + wv; q <= q_hi; q += nw) {
-    const int rows = geom[q].rows, nfull = geom[q].nfull;
-    // ---- S_q[j] = sum_{n = j (mod q)} x[n]
-    if (q >= 64) {
-      const int nchunks = (q + 63) >> 6;
-      int c0 = 0;
-      for (; c0 + 4 <= nchunks; c0 += 4) fold_store_group<T, 4, 2, LW>(xs, q, rows, nfull, c0, lane, sbuf);
-      switch (nchunks - c0) {
-        case 3: fold_store_group<T, 3, 2, LW>(xs, q, rows, nfull, c0, lane, sbuf); break;
-        case 2: fold_store_group<T, 2, 4, LW>(xs, q, rows, nfull, c0, lane, sbuf); break;
-        case 1: fold_store_group<T, 1, 8, LW>(xs, q, rows, nfull, c0, lane, sbuf); break;
-        default: break;
-      }
-    } else {
-      const double tot = wave_fold_small(xs, N, q, lane);  // row-split path, S_q[lane] in the lanes below q
-      if (lane < q) sbuf[lane] = tot;
-    }
+  // sbuf holds S_q: apply E_q in place, reduce to norms[q]
+  auto emit = [&](int q) {
     wave_sync();
+    const int rows = geom[q].rows, nfull = geom[q].nfull;
     // ---- E_q in place: for every prime r | q subtract the mean over the r cosets mod q/r
     for (int k = pr_off[q]; k < pr_off[q + 1]; ++k) {
       const int d = pr_d[k];  // q / r
@@ -964,6 +979,76 @@ __global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x
     acc = wave_sum(acc);
     if (lane == 0) orow[q] = acc;
     wave_sync();
+  };
+
+  // The pass plan of the norm sweeps (period_hip.hip): a pass at base b with m row classes gives
+  // S_b, S_2b (m >= 2) and S_4b (m == 4) for the loads of one fold.  Multi-class bases are <= q_hi/2
+  // <= 256 here (the class sums of the whole base fit in registers, rows past the window read the
+  // zero pad); larger q_hi falls back to single passes on the host side of the plan.
+  for (int i = wv; i < n_pass; i += nw) {
+    const int b = plan[i].p, m = plan[i].m;
+    const int rows = geom[b].rows, nfull = geom[b].nfull;
+    if (b < 64) {
+      const double tot = wave_fold_small(xs, N, b, lane);  // row-split path, S_b[lane] in the lanes below b
+      if (lane < b) sbuf[lane] = tot;
+      emit(b);
+    } else if (m <= 1) {
+      const int nchunks = (b + 63) >> 6;
+      int c0 = 0;
+      for (; c0 + 4 <= nchunks; c0 += 4) fold_store_group<T, 4, 2, LW>(xs, b, rows, nfull, c0, lane, sbuf);
+      switch (nchunks - c0) {
+        case 3: fold_store_group<T, 3, 2, LW>(xs, b, rows, nfull, c0, lane, sbuf); break;
+        case 2: fold_store_group<T, 2, 4, LW>(xs, b, rows, nfull, c0, lane, sbuf); break;
+        case 1: fold_store_group<T, 1, 8, LW>(xs, b, rows, nfull, c0, lane, sbuf); break;
+        default: break;
+      }
+      emit(b);
+    } else if (m == 2) {
+      double a[2][4];
+      ram_fold_classes<T, 2, 4, LW>(xs, N, b, rows, lane, a);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = 64 * c + lane;
+        if (j < b) {
+          sbuf[j] = a[0][c];
+          sbuf[j + b] = a[1][c];
+        }
+      }
+      emit(2 * b);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = 64 * c + lane;
+        if (j < b) sbuf[j] = a[0][c] + a[1][c];
+      }
+      emit(b);
+    } else {
+      double a[4][2];
+      ram_fold_classes<T, 4, 2, LW>(xs, N, b, rows, lane, a);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = 64 * c + lane;
+        if (j < b) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sbuf[j + u * b] = a[u][c];
+        }
+      }
+      emit(4 * b);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = 64 * c + lane;
+        if (j < b) {
+          sbuf[j] = a[0][c] + a[2][c];
+          sbuf[j + b] = a[1][c] + a[3][c];
+        }
+      }
+      emit(2 * b);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = 64 * c + lane;
+        if (j < b) sbuf[j] = (a[0][c] + a[2][c]) + (a[1][c] + a[3][c]);
+      }
+      emit(b);
+    }
   }
 }
 
