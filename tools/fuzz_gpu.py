@@ -23,8 +23,12 @@ def windows(rng, w, n):
 bad = 0; t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
 rng = np.random.default_rng(seed); trials = 0
+t_mark = time.time()
 while time.time() < t_end:
     trials += 1
+    if time.time() - t_mark > 60:  # a progress line per minute (a silent GPU job is taken to be hung)
+        t_mark = time.time()
+        print("...", trials, "trials,", bad, "mismatches", flush=True)
     n = int(rng.integers(8, 6000)); w = int(rng.integers(1, 3)); x = windows(rng, w, n)
     which = rng.integers(0, 13)
     try:
