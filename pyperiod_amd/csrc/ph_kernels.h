@@ -495,7 +495,10 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 //   and evaluate the reference's expression exactly (second pass) whenever the screen is
 //   within its own error bound of the threshold, so the accept decision is the exact one.
 // ======================================================================================
-constexpr int kS2LBatch = 64;  // periods screened speculatively per round (8 waves x 8 periods)
+// periods screened speculatively per round (8 waves x 4 periods).  Screens beyond an accepted
+// period are discarded, (batch - 1) / 2 of them per accept on average: 32 beats 64 (9.4 vs 9.9 ms
+// on the config-4 shard) and 16 / 24 / 48.
+constexpr int kS2LBatch = 32;
 
 template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
