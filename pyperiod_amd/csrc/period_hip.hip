@@ -786,12 +786,16 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   const size_t sz = elem_size(dtype);
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
-               carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+               carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) + carve_bytes(ph::kCandCap, 4) +
+               carve_bytes(ph::kCandCap, 8) + carve_bytes(1, sizeof(ph::CandCtl));
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W, &gbuf));
   void* gwin;
   PH_TRY(place_window(c, &lds, N + kPad, sz, W, &gwin));
   PH_TRY(check_lds(c, lds, N, "ph_best_correlation"));
+  const ph::PassPlan* plan = nullptr;
+  int n_pass = 0;
+  if (max_length - 1 >= 2) PH_TRY(prepare_plan(c, 2, max_length - 1, &plan, &n_pass));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, std::max(max_length, 2), &geom));
   ph::Tables tb{};
@@ -812,7 +816,8 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
     PH_TRY(allow_lds(kernel, lds));
     ProfScope ps_(c, "k_best_correlation");
     hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds, c->stream, (const T*)dx, N, num, max_length, ratio,
-                       kflags, tb, geom, (T*)gbuf, (T*)gwin, (uint32_t*)dper, (double*)dnrm, (T*)dbases, (int*)dstat);
+                       kflags, tb, geom, plan, n_pass, (T*)gbuf, (T*)gwin, (uint32_t*)dper, (double*)dnrm, (T*)dbases,
+                       (int*)dstat);
     return (int)PH_OK;
   }));
   PH_TRY(launch_check("k_best_correlation"));

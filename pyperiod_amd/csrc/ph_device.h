@@ -478,9 +478,20 @@ __device__ __forceinline__ void seg_group(typename Win<T, LDS>::ptr ptr, int p, 
       part[0] = MAXABS ? fmax(part[0], fabs(t)) : fma(t, t, part[0]);
     } else if (M == 2) {
       const double e = a[0][c], o = a[1 % M][c], t = e + o;
-      part[0] = fma(t, t, part[0]);
-      part[1] = fma(e, e, part[1]);
-      part[2] = fma(o, o, part[2]);
+      if (MAXABS) {  // max |S| of p and of 2p (screening values: S_p = e + o is not a row-order sum)
+        part[0] = fmax(part[0], fabs(t));
+        part[1] = fmax(part[1], fmax(fabs(e), fabs(o)));
+      } else {
+        part[0] = fma(t, t, part[0]);
+        part[1] = fma(e, e, part[1]);
+        part[2] = fma(o, o, part[2]);
+      }
+    } else if (MAXABS) {
+      const double e = a[0][c] + a[2 % M][c], o = a[1 % M][c] + a[3 % M][c], t = e + o;
+      part[0] = fmax(part[0], fabs(t));
+      part[1] = fmax(part[1], fmax(fabs(e), fabs(o)));
+#pragma unroll
+      for (int u = 0; u < M; ++u) part[2] = fmax(part[2], fabs(a[u][c]));
     } else {
       const double e = a[0][c] + a[2 % M][c], o = a[1 % M][c] + a[3 % M][c], t = e + o;
       part[0] = fma(t, t * wgt[0], part[0]);
@@ -609,14 +620,20 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
     if (M == 1) {
       total[0] = MAXABS ? fmax(total[0], sacc[0]) : fma(sacc[0], wgt[0], total[0]);
     } else if (M == 2) {
-      total[0] = fma(sacc[0], wgt[0], total[0]);
-      total[1] = fma(sacc[1], wgt[1], fma(sacc[2], wgt[2], total[1]));
+      if (MAXABS) {
+        total[0] = fmax(total[0], sacc[0]);
+        total[1] = fmax(total[1], sacc[1]);
+      } else {
+        total[0] = fma(sacc[0], wgt[0], total[0]);
+        total[1] = fma(sacc[1], wgt[1], fma(sacc[2], wgt[2], total[1]));
+      }
     }
   }
 }
 
 // The online 8-period butterfly of wave_sweep as a state machine, for producers that deliver
 // one to three periods at a time.  `k` is wave-uniform.
+template <bool MAXABS = false>
 struct Butterfly8 {
   double l1, l2, l3;
   int k, myp;
@@ -631,15 +648,15 @@ struct Butterfly8 {
     if ((k & 1) == 0) {
       l1 = a;
     } else {
-      a = butterfly_merge<false>(l1, a, 32, lane);
+      a = butterfly_merge<MAXABS>(l1, a, 32, lane);
       if ((k & 2) == 0) {
         l2 = a;
       } else {
-        a = butterfly_merge<false>(l2, a, 16, lane);
+        a = butterfly_merge<MAXABS>(l2, a, 16, lane);
         if ((k & 4) == 0) {
           l3 = a;
         } else {
-          const double tot = reduce8<false>(butterfly_merge<false>(l3, a, 8, lane));
+          const double tot = reduce8<MAXABS>(butterfly_merge<MAXABS>(l3, a, 8, lane));
           if (myp != 0) consume(tot, myp);
           myp = 0;
         }
@@ -656,24 +673,24 @@ struct Butterfly8 {
 // Norm sweep driven by a pass plan: visits ||P_q x||^2 of every period the passes
 // plan[i_first], plan[i_first + stride], ... (< i_end) produce.  Periods arrive out of order;
 // consume(value, q) runs in the 8 lanes that own q.
-template <typename T, bool LDS, typename F>
+template <typename T, bool LDS, bool MAXABS = false, typename F>
 __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end,
                                                 int stride, int lane, F&& consume) {
-  Butterfly8 bf;
+  Butterfly8<MAXABS> bf;
   bf.reset();
   for (int i = i_first; i < i_end; i += stride) {
     const int p = plan[i].p, m = plan[i].m;
     if (m <= 1) {
-      bf.push(wave_partial<T, false, LDS>(xs, N, p, geom[p], lane), p, lane, consume);
+      bf.push(wave_partial<T, MAXABS, LDS>(xs, N, p, geom[p], lane), p, lane, consume);
     } else if (m == 2) {
       double part[3];
-      wave_pass_seg<T, 2, false, LDS>(xs, p, geom, lane, part);
+      wave_pass_seg<T, 2, MAXABS, LDS>(xs, p, geom, lane, part);
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
     } else {
       double part[3];
-      wave_pass_seg<T, 4, false, LDS>(xs, p, geom, lane, part);
+      wave_pass_seg<T, 4, MAXABS, LDS>(xs, p, geom, lane, part);
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
       bf.push(part[2], 4 * p, lane, consume);

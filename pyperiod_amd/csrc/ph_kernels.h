@@ -627,10 +627,19 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // ======================================================================================
 // Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.
 // ======================================================================================
+constexpr int kCandCap = 256;  // screened candidates per sweep kept for exact evaluation
+
+struct CandCtl {
+  unsigned long long lbits;  // running lower bound on the best value (bits of a non-negative double)
+  int ncand;
+  int nsurv;
+};
+
 template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_best_correlation(const T* __restrict__ x, int N, int num,
                                                              int max_length, double ratio, unsigned flags,
                                                              Tables tb, const PGeom* __restrict__ geom,
+                                                             const PassPlan* __restrict__ plan, int n_pass,
                                                              T* __restrict__ gbuf, T* gwin,
                                                              uint32_t* __restrict__ periods_out,
                                                              double* __restrict__ norms_out,
@@ -644,6 +653,9 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   double* red = cv.take<double>(kRedDoubles);
   double* wbest = cv.take<double>(kMaxWaves);
   int* wbestp = cv.take<int>(kMaxWaves);
+  int* cand_q = cv.take<int>(kCandCap);
+  double* cand_hi = cv.take<double>(kCandCap);
+  CandCtl* ctl = cv.take<CandCtl>(1);
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -665,16 +677,73 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     double keep_n = 0.0;
     bool zero_row = true;
     if (status == 0) {
-      // argmax over (p, s) of |sum(x[s::p])|, strict '>' in p-major order (:324-331)
+      // argmax over (p, s) of |sum(x[s::p])|, strict '>' in p-major order (:324-331).
+      // Screen: the multi-period passes of the pass plan give max_s |S_p[s]| for up to three periods
+      // per fold, but from class sums, i.e. not in the reference's row order.  |S~ - S| <= R 2^-53
+      // sum|x| bounds the difference, so every period whose screened value is within that radius
+      // of the best is re-evaluated with the row-order pass and the exact values are compared.
+      double asum = 0.0;
+      for (int n = tid; n < N; n += blockDim.x) asum += fabs((double)work[n]);
+      asum = block_sum(asum, red);
+      if (tid == 0) {
+        ctl->lbits = 0ull;
+        ctl->ncand = 0;
+        ctl->nsurv = 0;
+      }
+      __syncthreads();
+      {
+        const double radius = 4.0 * 1.1102230246251565e-16 * asum;  // 4 * 2^-53 * sum|x| per row
+        double lrun = 0.0;
+        wave_sweep_plan<T, LW, true>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double v, int q) {
+          const double e = radius * (double)(geom[q].rows + 4);
+          const double hi = v + e, lo = v - e;
+          lrun = fmax(lrun, __longlong_as_double((long long)*(volatile unsigned long long*)&ctl->lbits));
+          if ((lane & 7) == 0 && hi > 0.0 && hi >= lrun) {
+            const int idx = atomicAdd(&ctl->ncand, 1);
+            if (idx < kCandCap) {
+              cand_q[idx] = q;
+              cand_hi[idx] = hi;
+            }
+          }
+          if (lo > lrun) {
+            lrun = lo;
+            if ((lane & 7) == 0) atomicMax(&ctl->lbits, (unsigned long long)__double_as_longlong(lo));
+          }
+        });
+      }
+      __syncthreads();
+      const int ncand = ctl->ncand;
       double best = 0.0;
       int bestp = 0;
-      wave_sweep<T, true, LW>(work, N, geom, 2 + wv, max_length - 1, nw, lane, [&](double v, int p) {
-        if (v > best) {
+      auto exact = [&](int q) {  // row-order sums, bit-identical to the reference's sum(x[s::q])
+        const double v = wave_max(wave_partial<T, true, LW>(work, N, q, geom[q], lane));
+        if (v > best || (v == best && bestp != 0 && q < bestp)) {
           best = v;
-          bestp = p;
+          bestp = q;
         }
-      });
-      wave_argmax(best, bestp);
+      };
+      if (ncand <= kCandCap) {
+        if (wv == 0) {  // survivors: upper bound reaches the final lower bound (compacted in place)
+          const double lfin = __longlong_as_double((long long)ctl->lbits);
+          int ns = 0;
+          for (int b = 0; b < ncand; b += kWave) {
+            const int k = b + lane;
+            const bool keep = k < ncand && cand_hi[k] >= lfin;
+            const int q = k < ncand ? cand_q[k] : 0;
+            const unsigned long long m = __ballot(keep);
+            const int pos = ns + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep) cand_q[pos] = q;
+            ns += __popcll(m);
+          }
+          if (lane == 0) ctl->nsurv = ns;
+        }
+        __syncthreads();
+        const int ns = ctl->nsurv;
+        for (int k = wv; k < ns; k += nw) exact(cand_q[k]);
+      } else {  // list overflow (many near-ties): every period exactly
+        for (int q = 2 + wv; q <= max_length - 1; q += nw) exact(q);
+      }
+      if (!(best > 0.0)) bestp = 0;
       if (lane == 0) {
         wbest[wv] = best;
         wbestp[wv] = bestp;
