@@ -76,6 +76,7 @@ struct ph_ctx {
   int plan_lo = -1, plan_hi = -1, plan_n = 0, plan_m = -1;
   int plan_max_m = 4;  // largest row-class count a pass may use (PH_PLAN_MAX_M overrides: 1, 2 or 4)
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
+  int step1_block = 0;               // k_mbest_step1 only: 0 = automatic (PH_STEP1_BLOCK overrides, <= 1024)
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
   int prof_n = 0;
@@ -447,6 +448,10 @@ int ph_create(int device, ph_ctx** out) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2 || v == 4) c->plan_max_m = v;
   }
+  if (const char* e = std::getenv("PH_STEP1_BLOCK")) {
+    const int v = std::atoi(e);
+    if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
+  }
   if (const char* e = std::getenv("PH_SWEEP_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 512 && v % 64 == 0) c->sweep_block = v;
@@ -698,7 +703,14 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     auto kernel = ph::k_mbest_step1<T, decltype(lw)::value>;
     PH_TRY(allow_lds(kernel, lds1));
     ProfScope ps_(c, "k_mbest_step1");
-    hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds1, c->stream, (const T*)dx, N, num, min_length,
+    // 16 wavefronts per window: two workgroups per CU at N = 4096 (-2.4 % against four of 8 waves),
+    // and long windows, which leave room for one or two workgroups per CU, still fill the SIMDs
+    // (N = 8192: -15 %, N = 16384: -23 %)
+    // (short windows, N < 3072, keep 8: four workgroups per CU there)
+    const int block1 = c->step1_block ? c->step1_block
+                       : (c->sweep_block == ph::kBlockWide && N >= 3072) ? 1024
+                                                                         : c->sweep_block;
+    hipLaunchKernelGGL(kernel, grid, dim3(block1), lds1, c->stream, (const T*)dx, N, num, min_length,
                        max_length, gamma, kflags, tb, geom, plan, n_pass, (T*)gbuf1, (T*)gwin1, max_iters,
                        (uint32_t*)dper, (double*)dpow, (T*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
     return (int)PH_OK;

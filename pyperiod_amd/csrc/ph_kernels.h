@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // distinct periods are found.  One workgroup per window, one launch per window batch.
 // ======================================================================================
 template <typename T, bool LW>
-__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1(const T* __restrict__ x, int N, int num, int p_lo,
                                                         int p_hi, int gamma, unsigned flags, Tables tb,
                                                         const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
