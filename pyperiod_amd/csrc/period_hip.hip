@@ -604,7 +604,9 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   const bool general = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) && mode != PH_SWEEP_MAXABS;
   size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8);
   const int P = p_hi - p_lo + 1;
-  const int chunks = pick_chunks(c, W, P, 8 * (c->sweep_block / 64));
+  // long windows (at most two workgroups per CU): 16 wavefronts per workgroup
+  const int sweep_block = (3 * lds > (size_t)c->lds_limit && c->sweep_block == ph::kBlockWide) ? 1024 : c->sweep_block;
+  const int chunks = pick_chunks(c, W, P, 8 * (sweep_block / 64));
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W * chunks, &gbuf));
   void* gwin;
@@ -629,7 +631,7 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
     auto kernel = ph::k_sweep<T, decltype(lw)::value>;
     PH_TRY(allow_lds(kernel, lds));
     ProfScope ps_(c, "k_sweep");
-    hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds, c->stream, (const T*)dx, N, p_lo, p_hi, mode, chunks,
+    hipLaunchKernelGGL(kernel, grid, dim3(sweep_block), lds, c->stream, (const T*)dx, N, p_lo, p_hi, mode, chunks,
                        kflags, tb, geom, plan, n_pass, (T*)gbuf, (T*)gwin, (double*)dout);
     return (int)PH_OK;
   }));

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_project_batch(const T* __restrict__ 
 //   the window load.  Flagged path: workgroup-cooperative full projection per period.
 // ======================================================================================
 template <typename T, bool LW>
-__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_sweep(const T* __restrict__ x, int N, int p_lo, int p_hi, int mode,
                                                       int chunks, unsigned flags, Tables tb,
                                                       const PGeom* __restrict__ geom,
                                                       const PassPlan* __restrict__ plan, int n_pass,
