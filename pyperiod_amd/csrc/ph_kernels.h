@@ -1339,23 +1339,15 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
           if (i >= pa) i -= pa;
         }
       }
-      // right-hand side: fold of the data (QOPeriods.py:782), rows in order, eight loads ahead
-      const T* ptr = data + j;
+    }
+    // right-hand side: fold of the data (QOPeriods.py:782), one wavefront per residue (a small period
+    // has few residues with many samples each: two threads summing 8192 samples cost 0.2 ms)
+    for (int j = wv; j < keep; j += nw) {
+      const int terms = (N - 1 - j) / bestp + 1;
       double sj = 0.0;
-      int r = 0;
-      for (; r + 8 <= terms; r += 8) {
-        T v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = ptr[(int64_t)u * bestp];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sj += (double)v[u];
-        ptr += (int64_t)8 * bestp;
-      }
-      for (; r < terms; ++r) {
-        sj += (double)ptr[0];
-        ptr += bestp;
-      }
-      rhs[row0 + j] = sj;
+      for (int r = lane; r < terms; r += kWave) sj += (double)data[j + (int64_t)r * bestp];
+      sj = wave_sum(sj);
+      if (lane == 0) rhs[row0 + j] = sj;
     }
     __threadfence_block();
     __syncthreads();
