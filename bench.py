@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: window-projections/s of the fused all-p sweep, BASELINE.json config 2.
+"""Benchmark of the pyPeriod projection hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One *step* = Periods.m_best(num=10) over one batch of 1024 synthetic windows x N=4096 fp64 per
-GPU, already resident in HBM: the step-1 kernel (repeated all-p sweep p = 2..N/3, argmax,
-subtract -- one launch per window batch) and the step-2 factor-refinement kernel.  A
-window-projection is one (window, candidate period) projection + norm of an all-p sweep
-(SURVEY.md 8d); winner re-projections and step-2 projections are performed but NOT counted,
-so the figure is conservative.  Windows are independent, so ranks never exchange data:
-"scaling" is weak (1024 windows per GPU).
+N = 1 -- BASELINE.json config 2, the configuration the metric is quoted on: one *step* =
+  Periods.m_best(num=10) over 1024 synthetic windows x N=4096 fp64 resident in HBM: the step-1
+  kernel (repeated all-p sweep p = 2..N/3, argmax, subtract -- one launch per window batch) and
+  the step-2 factor-refinement kernel.  A window-projection is one (window, candidate period)
+  projection + norm of an all-p sweep; winner re-projections and step-2
+  projections are performed but NOT counted.  The line also carries `c4_single_gpu`: BASELINE
+  config 4's whole batch (65 536 windows, small_to_large(0.05)) on this one GPU -- the
+  denominator of the strong-scaling target below.
+
+N > 1 -- BASELINE.json config 4 / BASELINE.md's scaling target, STRONG scaling: the whole batch
+  of 65 536 windows x N=4096 fp64 starts on rank 0; one step = RCCL scatter (pipelined in pieces,
+  pyperiod_amd/dist.py) -> small_to_large(0.05) on every rank's block -> RCCL gather of
+  counts / periods / powers to rank 0.  `value` = 65 536 x 2047 nominal window-projections per
+  step / wall time of the step (max over ranks), i.e. it includes the collectives.  Reported
+  beside it: the unpipelined phase times (scatter / compute / gather) and the same 65 536
+  windows on rank 0's GPU alone (`single_gpu`), so `speedup_vs_single_gpu` is the strong-scaling
+  ratio measured inside one run.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline     -- step-1 kernel: algorithmic bytes (32768 B per window-projection)
-                  / launch time from HIP events on the kernel's own stream, against 8 TB/s.
-                  The window lives in LDS, so this logical figure may exceed the HBM peak;
-                  `lds_frac` (vs ~150 TB/s of LDS read bandwidth) is the utilisation that
-                  actually binds, `traffic` the measured HBM bytes per launch (rocprofv3 PMC,
-                  profiles/) when available.
+  roofline     -- dominant kernel, launch time from HIP events on the kernel's own stream.
+                  The window lives in LDS, so the roof that binds is LDS read bandwidth
+                  (~150 TB/s aggregate ds_read_b64), not HBM: `achieved` = bytes the fold passes
+                  read from LDS per second (pass plan x N x 8 B, exact), `frac` <= 1.
+                  `logical_hbm_ratio` is SURVEY 8d's logical figure (N*8 B per window-projection
+                  / 8 TB/s; exceeds 1 because fusion works), `hbm_frac_measured` the rocprofv3
+                  HBM bytes per launch (`traffic`, recorded in profiles/ by a separate PMC run)
+                  / launch time / 8 TB/s.
   cpu_baseline -- the numpy oracle (a port of the reference) timed on the host cores of this
                   box on a bounded sample of the same windows (N=1 only).
 """
@@ -34,16 +46,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_SAMPLES = 4096
-WINDOWS_PER_GPU = 1024
+WINDOWS_PER_GPU = 1024  # config 2
 NUM_PERIODS = 10
+C4_WINDOWS = 65536  # config 4
+C4_THRESH = 0.05
+C4_CAP = 32  # accepted periods kept per window (15 on average, max 24 on this data); overflow is checked
 BYTES_PER_WINDOW_PROJECTION = N_SAMPLES * 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LDS_PEAK_GBS = 150000.0  # MI355X_MICROARCH.md LDS: ~150 TB/s aggregate ds_read_b64
 
 
 # ------------------------------------------------------------------------------------------
-# CPU baseline leg: the oracle, one window per call like the reference.  Runs in spawned
-# worker processes BEFORE this process touches the GPU.
+# host-side legs that must run BEFORE this process touches the GPU (they spawn workers)
 # ------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     w0, count, n, num = args
@@ -69,10 +83,16 @@ def _cpu_worker(args):
     return calls[0], dt
 
 
-def cpu_baseline(n, num, per_worker=6):
+def cpu_baseline(n, num, per_worker=8):
+    """The oracle on every host core of this box (one window per call, like the reference)."""
     import multiprocessing as mp
 
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    avail = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    cores = max(1, avail)
     ctx = mp.get_context("spawn")
     jobs = [(i * per_worker, per_worker, n, num) for i in range(cores)]
     t0 = time.perf_counter()
@@ -85,29 +105,71 @@ def cpu_baseline(n, num, per_worker=6):
         "value": projections / busy,
         "unit": "window-projections/s",
         "cores": cores,
+        "os_cpu_count": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle m_best(num={num}) on windows 0..{cores * per_worker - 1} (N={n}), "
-        f"{per_worker} per core, {projections} projections, {busy:.1f} s busy / {wall:.1f} s wall",
+        f"{per_worker} per core on {cores} cores, {projections} projections, {busy:.1f} s busy / {wall:.1f} s wall",
         "per_core": projections / busy / cores,
+        "reference_per_core_survey": 6178.0,  # the reference itself, 1 Xeon core (different machine), BASELINE.md
     }
 
 
-def load_recorded_traffic():
-    """HBM bytes per step-1 launch measured with rocprofv3 --pmc (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes, + WRITE_SIZE); recorded in profiles/ by the profiling run."""
+def _synth_worker(args):
+    from pyperiod_amd.synth import multi_sinusoid_batch
+
+    w0, count, n = args
+    return w0, multi_sinusoid_batch(w0, count, n)
+
+
+def synth_windows(total, n, procs=None):
+    """Windows 0..total-1 of the seeded generator, built by a pool of host processes."""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    if procs is None:
+        try:
+            procs = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            procs = os.cpu_count() or 1
+        procs = max(1, min(procs, 32))
+    out = np.empty((total, n), dtype=np.float64)
+    chunk = 1024
+    jobs = [(w0, min(chunk, total - w0), n) for w0 in range(0, total, chunk)]
+    if procs == 1:
+        for job in jobs:
+            w0, blk = _synth_worker(job)
+            out[w0 : w0 + blk.shape[0]] = blk
+        return out
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(procs) as pool:
+        for w0, blk in pool.imap_unordered(_synth_worker, jobs):
+            out[w0 : w0 + blk.shape[0]] = blk
+    return out
+
+
+def load_recorded_traffic(kernel):
+    """HBM bytes per launch of `kernel` measured with rocprofv3 --pmc (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes, + WRITE_SIZE) in a separate profiling run; profiles/traffic.json."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
-        if rec.get("workload") == workload_name():
-            return rec.get("hbm_bytes_per_launch")
+        ent = rec.get("kernels", {}).get(kernel)
+        if ent:
+            return ent.get("hbm_bytes_per_launch"), ent.get("source")
     except (OSError, ValueError):
         pass
-    return None
+    return None, None
 
 
-def workload_name():
-    return f"m_best(num={NUM_PERIODS}) all-p sweep p=2..{N_SAMPLES // 3}, {WINDOWS_PER_GPU} windows x N={N_SAMPLES} fp64 per GPU"
+def c2_workload():
+    return f"config 2: m_best(num={NUM_PERIODS}) all-p sweep p=2..{N_SAMPLES // 3}, {WINDOWS_PER_GPU} windows x N={N_SAMPLES} fp64 per GPU"
+
+
+def c4_workload(world):
+    return (f"config 4: small_to_large(thresh={C4_THRESH}) p=2..{N_SAMPLES // 2}, {C4_WINDOWS} windows x N={N_SAMPLES} fp64, "
+            f"batch on rank 0 -> RCCL scatter -> compute on {world} GPU(s) -> RCCL gather")
 
 
 def main():
@@ -116,10 +178,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--root-leg", action="store_true",
-                    help="N > 1: also time the batch-on-rank-0 deployment shape (RCCL scatter -> m_best -> gather), "
-                         "reported separately, never part of `value`")
-    ap.add_argument("--no-root-leg", action="store_true", help=argparse.SUPPRESS)  # accepted, the leg is opt-in now
+    ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4 single-GPU leg")
+    ap.add_argument("--c4-windows", type=int, default=C4_WINDOWS, help="rehearsals only; the reported config is 65536")
+    ap.add_argument("--pieces", type=int, default=4, help="N>1: pieces the scatter of each rank's block is cut into")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -128,14 +189,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    # ---- host-only legs first: nothing below this block may fork/spawn after a HIP call
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(N_SAMPLES, NUM_PERIODS)  # before any HIP call in this process
+    x4_host = None
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(N_SAMPLES, NUM_PERIODS)
+        if world > 1 or not args.no_c4:
+            x4_host = synth_windows(args.c4_windows, N_SAMPLES)
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
+
+    ndev = max(1, torch.cuda.device_count())  # does not initialise the GPU
+    dev_index = local_rank % ndev  # == local_rank on a full node
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the process group is created before any other GPU work of this process
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    torch.cuda.set_device(dev_index)
 
     import __graft_entry__ as ge
 
@@ -143,133 +222,242 @@ def main():
     from pyperiod_amd import PeriodEngine
     from pyperiod_amd.synth import multi_sinusoid_batch
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dev_index = local_rank % max(1, torch.cuda.device_count())  # == local_rank on a full node
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
     eng = PeriodEngine(dev_index)
-    # windows rank*1024 .. rank*1024+1023 of the seeded generator; resident in HBM before t0
-    x_host = multi_sinusoid_batch(rank * WINDOWS_PER_GPU, WINDOWS_PER_GPU, N_SAMPLES)
-    x = torch.from_numpy(x_host).to(dev)
-    P = N_SAMPLES // 3 - 2 + 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def step():
-        return eng.m_best(x, NUM_PERIODS, None, 2, False, want_sweeps=True)
+    def kernel_ms(prof, name):
+        v = [ms for nm, ms in prof if nm == name]
+        return sum(v) / max(1, len(v)), len(v)
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    eng.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile(False)
+    def c4_compute(xl):
+        counts, per, pw, _, st = eng.small_to_large(xl, C4_THRESH, None, False, False, cap=C4_CAP, want_bases=False,
+                                                    nosync=True)
+        return counts, per, pw, st
 
-    periods, powers, bases, status, sweeps = out
-    assert int(status.abs().sum().item()) == 0, "a window failed in m_best"
+    line = None
+    if world == 1:
+        # =============================== config 2 (headline) ===============================
+        x = torch.from_numpy(multi_sinusoid_batch(0, WINDOWS_PER_GPU, N_SAMPLES)).to(dev)
+        P = N_SAMPLES // 3 - 2 + 1
+        n_pass, n_per = eng.sweep_plan_info(2, N_SAMPLES // 3)
+        assert n_per == P
 
-    # Optional second leg (N > 1 only, outside the timed region): the batch starts on rank 0,
-    # is scattered with RCCL, processed, and the fixed-shape results are gathered back --
-    # the "RCCL scatter/gather over xGMI" deployment shape.  Never part of `value`.
-    root_leg = None
-    if world > 1 and args.root_leg and not args.no_root_leg:
-        try:
-            from pyperiod_amd.dist import gather_rows, scatter_windows
+        def step():
+            return eng.m_best(x, NUM_PERIODS, None, 2, False, want_sweeps=True)
 
-            total = world * WINDOWS_PER_GPU
-            x_root = torch.cat([x] * world, 0) if rank == 0 else None  # synthetic: rank 0's windows repeated
-            barrier()
-            t1 = time.perf_counter()
-            xl = scatter_windows(x_root, total, N_SAMPLES, torch.float64, dev)
-            torch.cuda.synchronize(dev)
-            t2 = time.perf_counter()
-            o = eng.m_best(xl, NUM_PERIODS, None, 2, False)
-            torch.cuda.synchronize(dev)
-            t3 = time.perf_counter()
-            g_per = gather_rows(o[0], total)
-            g_pow = gather_rows(o[1], total)
-            barrier()
-            t4 = time.perf_counter()
-            root_leg = {"scatter_ms": 1e3 * (t2 - t1), "compute_ms": 1e3 * (t3 - t2), "gather_ms": 1e3 * (t4 - t3),
-                        "total_ms": 1e3 * (t4 - t1), "windows": total,
-                        "note": "input on rank 0 -> RCCL scatter -> m_best -> RCCL gather of periods/powers"}
-            if rank == 0:
-                assert g_per.shape == (total, NUM_PERIODS) and g_pow.shape == (total, NUM_PERIODS)
-        except Exception as exc:  # the headline number must survive a failure of this leg
-            root_leg = {"error": repr(exc)}
-    proj_local = int(sweeps.sum().item()) * P  # per step on this rank
-    tproj = torch.tensor([float(proj_local)], device=dev, dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tproj, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    proj_total = float(tproj.item())
-    elapsed = float(tmax.item())
-
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = proj_total * args.steps / elapsed
-        k1 = [ms for name, ms in prof if name == "k_mbest_step1"]
-        k2 = [ms for name, ms in prof if name == "k_mbest_step2"]
-        k1_ms = sum(k1) / max(1, len(k1))
-        alg_bytes = proj_local * BYTES_PER_WINDOW_PROJECTION
-        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile(False)
+        periods, powers, bases, status, sweeps = out
+        assert int(status.abs().sum().item()) == 0, "a window failed in m_best"
+        n_sweeps = int(sweeps.sum().item())
+        proj = n_sweeps * P  # per step
+        k1_ms, _ = kernel_ms(prof, "k_mbest_step1")
+        k2_ms, _ = kernel_ms(prof, "k_mbest_step2")
+        logical = proj * BYTES_PER_WINDOW_PROJECTION  # SURVEY 8d, per launch
+        lds_bytes = n_sweeps * n_pass * BYTES_PER_WINDOW_PROJECTION  # what the fold passes read from LDS
+        traffic, tsrc = load_recorded_traffic("k_mbest_step1")
+        sec = k1_ms * 1e-3
         line = {
             "metric": "window-projections/sec (all-p sweep, N=4096)",
-            "value": value,
+            "value": proj * args.steps / elapsed,
             "unit": "window-projections/s",
-            "n_gpus": world,
+            "n_gpus": 1,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic (3 sinusoids + 5 % noise, numpy default_rng(1000 + w), SURVEY 8d)",
             "config": {
-                "workload": workload_name(),
+                "workload": c2_workload(),
                 "windows_per_gpu": WINDOWS_PER_GPU,
                 "n_samples": N_SAMPLES,
                 "periods_swept": P,
-                "sweeps_per_window_mean": float(sweeps.double().mean().item()),
-                "parallelism": f"windows sharded over {world} GPU(s), no data-path collective",
+                "passes_per_sweep": n_pass,
+                "sweeps_per_window_mean": n_sweeps / WINDOWS_PER_GPU,
+                "parallelism": "one process per GPU; windows are independent, no data-path collective at N=1",
             },
             "roofline": {
                 "kernel": "k_mbest_step1<double, true>",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
+                "bound": "lds",
+                "achieved": lds_bytes / sec / 1e9 if sec > 0 else 0.0,
+                "peak": LDS_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_recorded_traffic(),
-                "algorithmic_bytes_per_launch": alg_bytes,
+                "frac": lds_bytes / sec / 1e9 / LDS_PEAK_GBS if sec > 0 else 0.0,
+                "achieved_definition": "bytes the fold passes read from LDS per launch (sweeps x passes_per_sweep x N x 8 B; "
+                "one pass yields up to 3 periods) / launch time",
                 "launch_ms": k1_ms,
-                "step2_launch_ms": sum(k2) / max(1, len(k2)),
-                "lds_frac": achieved / LDS_PEAK_GBS,
-                "note": "logical bytes (N*8 per window-projection); the window is LDS-resident, so frac can exceed 1 -- lds_frac is the binding utilisation",
+                "step2_launch_ms": k2_ms,
+                "lds_bytes_per_launch": lds_bytes,
+                "algorithmic_bytes_per_launch": logical,
+                "logical_GBs": logical / sec / 1e9 if sec > 0 else 0.0,
+                "logical_hbm_ratio": logical / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+                "logical_lds_ratio": logical / sec / 1e9 / LDS_PEAK_GBS if sec > 0 else 0.0,
+                "traffic": traffic,
+                "traffic_recorded": True,
+                "traffic_source": tsrc,
+                "hbm_frac_measured": (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic and sec > 0) else None,
+                "compulsory_hbm_bytes_per_launch": WINDOWS_PER_GPU * N_SAMPLES * 8 * (1 + NUM_PERIODS),
+                "note": "SURVEY 8d's logical figure (N*8 B per window-projection against 8 TB/s) is kept as logical_hbm_ratio; it "
+                "exceeds 1 because the fused sweep serves every pass but the first from LDS.  The binding roof is LDS read "
+                "bandwidth / VALU issue; frac is the LDS utilisation.",
             },
             "cpu_baseline": cpu,
         }
-        if root_leg is not None:
-            line["rccl_root_leg"] = root_leg
         if cpu:
-            line["gpu_over_cpu"] = value / cpu["value"]
+            line["gpu_over_cpu"] = line["value"] / cpu["value"]
+        del x, out, periods, powers, bases
+        # =============================== config 4 on this one GPU ===============================
+        if x4_host is not None:
+            x4 = torch.from_numpy(x4_host).to(dev)
+            c4_compute(x4[:1024])
+            torch.cuda.synchronize(dev)
+            eng.profile(True)
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                o4 = c4_compute(x4)
+            torch.cuda.synchronize(dev)
+            ms4 = 1e3 * (time.perf_counter() - t0) / reps
+            k4_ms, _ = kernel_ms(eng.profile_read(), "k_small_to_large")
+            eng.profile(False)
+            assert int(o4[3].abs().max().item()) == 0, "small_to_large: capacity exceeded"
+            units = x4.shape[0] * (N_SAMPLES // 2 - 1)
+            line["c4_single_gpu"] = {
+                "workload": f"config 4 on one GPU: small_to_large({C4_THRESH}), {x4.shape[0]} windows x N={N_SAMPLES}, resident in HBM",
+                "ms": ms4,
+                "kernel_ms": k4_ms,
+                "window_projections_per_s": units / (ms4 * 1e-3),
+                "accepted_periods_mean": float(o4[0].double().mean().item()),
+                "logical_lds_ratio": units * BYTES_PER_WINDOW_PROJECTION / (k4_ms * 1e-3) / 1e9 / LDS_PEAK_GBS if k4_ms else None,
+            }
+    else:
+        # =============================== config 4, strong scaling ===============================
+        from pyperiod_amd.dist import gather_rows, run_sharded_pipelined, scatter_windows
+
+        total = args.c4_windows
+        x_root = torch.from_numpy(x4_host).to(dev) if rank == 0 else None
+        del x4_host
+
+        def step():
+            return run_sharded_pipelined(c4_compute, x_root, total, N_SAMPLES, torch.float64, dev, pieces=args.pieces)
+
+        for _ in range(args.warmup):
+            res = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+        # phase breakdown, unpipelined, outside the timed region (host clock, max over ranks)
+        barrier()
+        t1 = time.perf_counter()
+        xl = scatter_windows(x_root, total, N_SAMPLES, torch.float64, dev)
+        barrier()
+        t2 = time.perf_counter()
+        eng.profile(True)
+        o = c4_compute(xl)
+        barrier()
+        t3 = time.perf_counter()
+        k_ms, _ = kernel_ms(eng.profile_read(), "k_small_to_large")
+        eng.profile(False)
+        g = [gather_rows(t, total) for t in o]
+        barrier()
+        t4 = time.perf_counter()
+        kmax = torch.tensor([k_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+
+        single = None
+        if rank == 0:
+            counts, per, pw, st = res
+            assert counts.shape == (total,) and per.shape == (total, C4_CAP) and pw.shape == (total, C4_CAP)
+            assert int(st.abs().max().item()) == 0, "small_to_large: capacity exceeded"
+            assert torch.equal(counts, g[0]) and torch.equal(per, g[1])  # pipelined == unpipelined
+            c4_compute(x_root[:1024])
+            torch.cuda.synchronize(dev)
+            reps = 3
+            ts = time.perf_counter()
+            for _ in range(reps):
+                o1 = c4_compute(x_root)
+            torch.cuda.synchronize(dev)
+            single_ms = 1e3 * (time.perf_counter() - ts) / reps
+            assert torch.equal(o1[0], counts) and torch.equal(o1[1], per)  # sharded == one GPU
+            single = {"ms": single_ms, "window_projections_per_s": total * (N_SAMPLES // 2 - 1) / (single_ms * 1e-3),
+                      "note": "the same batch on rank 0's GPU alone, input resident, no collective"}
+        barrier()
+        if rank == 0:
+            units = total * (N_SAMPLES // 2 - 1)  # nominal projections per step
+            ms_per_step = 1e3 * elapsed / args.steps
+            per_gpu_units = -(-total // world) * (N_SAMPLES // 2 - 1)
+            kms = float(kmax.item())
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+            except Exception:  # noqa: BLE001
+                rccl = None
+            line = {
+                "metric": "window-projections/sec (all-p sweep, N=4096)",
+                "value": units * args.steps / elapsed,
+                "unit": "window-projections/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": ms_per_step,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic (3 sinusoids + 5 % noise, numpy default_rng(1000 + w), SURVEY 8d)",
+                "config": {
+                    "workload": c4_workload(world),
+                    "total_windows": total,
+                    "n_samples": N_SAMPLES,
+                    "periods_swept": N_SAMPLES // 2 - 1,
+                    "scatter_pieces": args.pieces,
+                    "parallelism": f"contiguous blocks of {-(-total // world)} windows per rank; scatter + gather only, no all-reduce",
+                    "backend": args.backend,
+                    "world_size": dist.get_world_size(),
+                    "rccl_version": rccl,
+                },
+                "phases_unpipelined_ms": {"scatter": 1e3 * (t2 - t1), "compute": 1e3 * (t3 - t2), "gather": 1e3 * (t4 - t3),
+                                          "sum": 1e3 * (t4 - t1)},
+                "single_gpu": single,
+                "speedup_vs_single_gpu": single["ms"] / ms_per_step,
+                "roofline": {
+                    "kernel": "k_small_to_large<double, true>",
+                    "bound": "lds",
+                    "achieved": per_gpu_units * BYTES_PER_WINDOW_PROJECTION / (kms * 1e-3) / 1e9 if kms else 0.0,
+                    "peak": LDS_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": per_gpu_units * BYTES_PER_WINDOW_PROJECTION / (kms * 1e-3) / 1e9 / LDS_PEAK_GBS if kms else 0.0,
+                    "achieved_definition": "nominal screen passes (one per candidate period) x N x 8 B read from LDS per launch / "
+                    "launch time of the slowest rank; re-screens after an accepted period are not counted",
+                    "launch_ms": kms,
+                    "traffic": None,
+                    "logical_hbm_ratio": per_gpu_units * BYTES_PER_WINDOW_PROJECTION / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else 0.0,
+                },
+                "cpu_baseline": None,
+            }
+    if line is not None:
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -57,6 +57,7 @@ extern "C" {
 #define PH_FLAG_ORTH 2u   /* orthogonalize (Periods.py:208-214); needs orth tables */
 #define PH_FLAG_SINGLE 4u /* return_single_period (Periods.py:216-217): only out[..., :p] written */
 #define PH_FLAG_DEVICE 8u /* array arguments are device pointers, call is asynchronous */
+#define PH_FLAG_NOSYNC 16u /* with PH_FLAG_DEVICE: never synchronise, not even to report PH_E_CAP */
 
 /* sweep modes */
 #define PH_SWEEP_NORM 0       /* periodic_norm(project(x,p))        Periods.py:507-508 */
@@ -104,6 +105,12 @@ int ph_device_info(ph_ctx* ctx, int* num_cu, int* lds_bytes);
  * fold_sums and orth_powers.  `flags` is ignored. */
 int ph_max_window(ph_ctx* ctx, int dtype, unsigned flags, int* max_n);
 
+/* Pass plan of the norm sweeps (ph_sweep norm modes, ph_m_best, ph_qo_find_periods) over the
+ * candidate periods [p_lo, p_hi]: n_periods = p_hi - p_lo + 1 periods are produced by n_pass
+ * passes over the LDS-resident window (a pass at base period p also yields the folds of 2p
+ * and 4p).  n_pass * N * sizeof(T) is the number of bytes one sweep reads from LDS. */
+int ph_sweep_plan_info(ph_ctx* ctx, int p_lo, int p_hi, int* n_pass, int* n_periods);
+
 /* ---- Periods.periodic_norm over a batch (Periods.py:221-241) ---------------------------
  * out[w] = ||x[w]||_2 / sqrt(N), additionally / sqrt(p) when p > 0.  Any N. */
 int ph_periodic_norm(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int p,
@@ -144,7 +151,10 @@ int ph_m_best(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int num,
  * counts (W) int32 = number of accepted periods; periods (W, cap) int32; powers (W, cap)
  * float64; bases (W, cap, N) dtype of x or NULL.  Windows that accept more than `cap`
  * periods get status PH_ST_CAP, counts[w] holds the true count, and the call returns
- * PH_E_CAP so that the host can retry with a larger cap.  n_periods < 0 = floor(N/2). */
+ * PH_E_CAP so that the host can retry with a larger cap -- also with PH_FLAG_DEVICE: the
+ * library then reads the batch's largest count back (one word; the call synchronises the
+ * stream).  PH_FLAG_DEVICE | PH_FLAG_NOSYNC keeps the call asynchronous and returns PH_OK;
+ * the caller must then inspect `status`.  n_periods < 0 = floor(N/2). */
 int ph_small_to_large(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, double thresh,
                       int n_periods, const int32_t* orth_off, const int32_t* orth_q,
                       int table_max_p, unsigned flags, int cap, int32_t* counts,
@@ -202,6 +212,11 @@ int ph_qo_find_periods(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, 
                        double thresh, int min_length, int max_length, int kcap, unsigned flags,
                        uint32_t* periods, double* norms, int32_t* keeps, int32_t* counts,
                        double* weights, void* residual, int32_t* status);
+
+/* *ok = 1 when ph_qo_find_periods can run windows of N samples of `dtype` with `kcap` dictionary
+ * rows on this device (window, solve vector and at least one Cholesky panel column fit the
+ * workgroup's LDS), else 0 -- callers fall back to a host-driven loop instead of catching PH_E_ARG. */
+int ph_qo_feasible(ph_ctx* ctx, int dtype, int N, int max_length, int kcap, int* ok);
 
 /* ---- QOPeriods.get_best_period_orthogonal / eq_3 / auto_corr (QOPeriods.py:1122-1232) -----
  * powers (W, max_p) float64: the Muresan-Parks orthogonal period powers `pows` for q < max_p

@@ -405,6 +405,21 @@ def ramanujan_norms_folded(x, min_length=2, max_length=None) -> np.ndarray:
     return norms
 
 
+def ramanujan_find_periods_with_weights(x, min_length=2, max_length=None, thresh=0.2, norms=None):
+    """RamanujanPeriods.find_periods_with_weights (:88-122) as intended: the v1 tree dies on a
+    missing ``_k`` and unpacks solve_quadratic's (weights, reconstruction) the wrong way round
+    (:109); tests/golden/make_golden.py (shim 4) runs the reference with those two repaired.
+    ``norms`` may be handed in (the float32-accumulated reference values decide the threshold
+    test at :95-99; by default the fp64 folded form is used)."""
+    if norms is None:
+        norms = ramanujan_norms_folded(x, min_length, max_length)
+    periods = np.argwhere(norms / np.abs(np.max(norms)) > thresh).flatten()  # :95-99
+    a, dims = qo_get_subspaces(periods, len(x))  # :106-108
+    w, recon = qo_solve_quadratic(x, a)  # :109-111
+    out = {"periods": periods, "norms": norms[periods], "subspaces": a, "weights": w, "basis_dictionary": dims}
+    return out, x - recon
+
+
 # --------------------------------------------------------------------------------------
 # QOPeriods pieces on the path (QOPeriods.py:598-643,743-852,940-1003)
 # --------------------------------------------------------------------------------------

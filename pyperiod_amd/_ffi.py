@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PYPERIOD_AMD_LIB") or os.path.join(_HERE, LIB_NAME)  
 
 PH_OK, PH_E_ARG, PH_E_HIP, PH_E_NOMEM, PH_E_CAP, PH_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 PH_F64, PH_F32 = 0, 1
-PH_FLAG_TRUNC, PH_FLAG_ORTH, PH_FLAG_SINGLE, PH_FLAG_DEVICE = 1, 2, 4, 8
+PH_FLAG_TRUNC, PH_FLAG_ORTH, PH_FLAG_SINGLE, PH_FLAG_DEVICE, PH_FLAG_NOSYNC = 1, 2, 4, 8, 16
 PH_STREAM_DEFAULT = 1  # ph_set_stream handle of the device default stream (its real handle, 0, means "own stream")
 PH_SWEEP_NORM, PH_SWEEP_NORM_GAMMA, PH_SWEEP_MAXABS = 0, 1, 2
 PH_ST_OK, PH_ST_NO_PERIOD, PH_ST_ITER_CAP, PH_ST_CAP = 0, 1, 2, 3
@@ -36,6 +36,7 @@ SIGNATURES = {
     "ph_timer_end": [_vp, C.POINTER(C.c_float)],
     "ph_device_info": [_vp, C.POINTER(_i), C.POINTER(_i)],
     "ph_max_window": [_vp, _i, _u, C.POINTER(_i)],
+    "ph_sweep_plan_info": [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i)],
     "ph_periodic_norm": [_vp, _vp, _i, _i64, _i, _i, _u, _vp],
     "ph_project_batch": [_vp, _vp, _i, _i64, _i, _pi32, _i, _pi32, _pi32, _i, _u, _vp],
     "ph_sweep": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _pi32, _pi32, _i, _u, _vp],
@@ -48,6 +49,7 @@ SIGNATURES = {
     "ph_ramanujan_norms": [_vp, _vp, _i, _i64, _i, _i, _i, _u, _vp],
     "ph_dict_project": [_vp, _vp, _vp, _i, _i, _u, _vp],
     "ph_qo_find_periods": [_vp, _vp, _i, _i64, _i, _i, _d, _i, _i, _i, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ph_qo_feasible": [_vp, _i, _i, _i, _i, C.POINTER(_i)],
     "ph_orth_powers": [_vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _vp, _vp],
     "ph_fold_sums": [_vp, _vp, _i, _i64, _i, _pi32, _pi32, _i, _u, _vp],
     "ph_tile_sum": [_vp, _vp, _i64, _i, _pi32, _pi32, _i, _i, _u, _vp],

@@ -129,13 +129,7 @@ size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
 // Pass plan of a norm sweep over [p_lo, p_hi]: every period is produced exactly once, either
 // by its own pass or as 2p / 4p of a smaller base period (see PassPlan in ph_device.h).
 // Periods below 64 use the row-split path one at a time (m = 0).
-int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4) {
-  max_m = std::min(max_m, c->plan_max_m);
-  if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi && c->plan_m == max_m) {
-    *out = static_cast<const ph::PassPlan*>(c->plan.p);
-    *n_pass = c->plan_n;
-    return PH_OK;
-  }
+std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m) {
   std::vector<ph::PassPlan> host;
   std::vector<char> covered((size_t)p_hi + 1, 0);
   for (int p = p_lo; p <= p_hi; ++p) {
@@ -173,6 +167,17 @@ int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n
       if (e.m == want) kept.push_back(e);
     host.swap(kept);
   }
+  return host;
+}
+
+int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4) {
+  max_m = std::min(max_m, c->plan_max_m);
+  if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi && c->plan_m == max_m) {
+    *out = static_cast<const ph::PassPlan*>(c->plan.p);
+    *n_pass = c->plan_n;
+    return PH_OK;
+  }
+  const std::vector<ph::PassPlan> host = build_plan(p_lo, p_hi, max_m);
   PH_HIP(hipStreamSynchronize(c->stream));
   PH_TRY(ensure(c, c->plan, std::max<size_t>(1, host.size()) * sizeof(ph::PassPlan)));
   if (!host.empty())
@@ -394,6 +399,27 @@ using ph::kPad;
 using ph::kMaxWaves;
 using ph::kRedDoubles;
 
+// LDS layout of k_qo_find: everything but the Cholesky panel, then a panel as wide as the remaining
+// LDS allows (<= kQoPanelMax columns of kcap + 1 rows).
+int qo_lds_layout(ph_ctx* c, size_t sz, int N, int max_length, int kcap, size_t* lds_out, int* nbw_out) {
+  size_t lds = carve_bytes(N + kPad, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+               carve_bytes(kMaxWaves, 4) + 2 * carve_bytes(ph::kQoMaxBlocks, 4) +
+               carve_bytes(ph::kQoMaxBlocks + 1, 4) + carve_bytes(ph::kQoMaxBlocks, 8) +
+               carve_bytes((max_length + 32) / 32, 4) + carve_bytes(kcap, 8) +
+               carve_bytes((size_t)ph::kQoTile * ph::kQoPanelMax, 8) +
+               carve_bytes((size_t)kMaxWaves * ph::kQoPanelMax, 8);
+  PH_TRY(check_lds(c, lds, N, "ph_qo_find_periods"));
+  const size_t ldp = (size_t)((kcap + 1) | 1);
+  const size_t room = (size_t)c->lds_limit > lds + 64 ? (size_t)c->lds_limit - lds - 64 : 0;
+  const int nbw = (int)std::min<size_t>(ph::kQoPanelMax, room / (ldp * 8));
+  if (nbw < 1)
+    return fail(PH_E_ARG, "ph_qo_find_periods: N=%d and kcap=%d leave no LDS for a Cholesky panel (limit %d B)", N,
+                kcap, c->lds_limit);
+  *lds_out = lds + carve_bytes(ldp * nbw, 8);
+  *nbw_out = nbw;
+  return PH_OK;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -481,11 +507,26 @@ int ph_destroy(ph_ctx* c) {
 
 int ph_set_stream(ph_ctx* c, void* hip_stream) {
   if (!c) return fail(PH_E_ARG, "ctx is NULL");
-  PH_HIP(hipStreamSynchronize(c->stream));
+  // drain the old stream, but rebind even if that fails (a borrowed stream may have been destroyed:
+  // the context must not stay stuck on it); the error is reported after the switch
+  const hipError_t e = hipStreamSynchronize(c->stream);
   if (hip_stream == PH_STREAM_DEFAULT)
     c->stream = nullptr;  // the legacy default stream
   else
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(PH_E_HIP, "ph_set_stream: draining the previous stream failed (%s); the new stream is bound",
+                hipGetErrorString(e));
+  }
+  return PH_OK;
+}
+
+int ph_sweep_plan_info(ph_ctx* c, int p_lo, int p_hi, int* n_pass, int* n_periods) {
+  if (!c || !n_pass || !n_periods) return fail(PH_E_ARG, "NULL argument");
+  if (p_lo < 1 || p_hi < p_lo) return fail(PH_E_ARG, "need 1 <= p_lo <= p_hi (got %d, %d)", p_lo, p_hi);
+  *n_pass = (int)build_plan(p_lo, p_hi, c->plan_max_m).size();
+  *n_periods = p_hi - p_lo + 1;
   return PH_OK;
 }
 
@@ -657,8 +698,11 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   size_t lds1 = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
                 carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) + carve_bytes(num, 8) +
                 carve_bytes(num, 4) + carve_bytes((P + 31) / 32, 4);
+  if (!fac_off || !fac_q) return fail(PH_E_ARG, "fac_off/fac_q tables are required");
+  if (table_max_p < max_length)
+    return fail(PH_E_ARG, "factor tables cover p <= %d, need %d", table_max_p, max_length);
   int max_fac = 1;  // most proper divisors any candidate period has
-  for (int q = 0; q <= max_length; ++q) max_fac = std::max(max_fac, fac_off ? fac_off[q + 1] - fac_off[q] : 0);
+  for (int q = 0; q <= max_length; ++q) max_fac = std::max(max_fac, fac_off[q + 1] - fac_off[q]);
   size_t lds2 = carve_bytes(N + kPad, sz) + carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) +
                 carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8);
   void *gbuf1, *gbuf2;
@@ -766,6 +810,9 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   PH_TRY(st.out(B_OUT4, status, (size_t)W * sizeof(int32_t), &dstat));
   PH_HIP(hipMemsetAsync(dper, 0, (size_t)W * cap * sizeof(int32_t), c->stream));
   PH_HIP(hipMemsetAsync(dpow, 0, (size_t)W * cap * sizeof(double), c->stream));
+  PH_TRY(ensure(c, c->buf[B_GEN0], 256));
+  int* dmax = static_cast<int*>(c->buf[B_GEN0].p);  // largest count of the batch (device word)
+  PH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), c->stream));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
   PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
@@ -775,14 +822,18 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
     ProfScope ps_(c, "k_small_to_large");
     hipLaunchKernelGGL(kernel, grid, dim3(c->sweep_block), lds, c->stream, (const T*)dx, N, thresh, n_periods, kflags,
                        tb, geom, (T*)gbuf, (T*)gwin, cap, (int*)dcnt, (int*)dper, (double*)dpow, (T*)dbases,
-                       (int*)dstat);
+                       (int*)dstat, dmax);
     return (int)PH_OK;
   }));
   PH_TRY(launch_check("k_small_to_large"));
   PH_TRY(st.finish());
-  if (!(flags & PH_FLAG_DEVICE)) {
+  // Capacity overflow must be impossible to miss: host-pointer calls are synchronous anyway; a
+  // device-pointer call reads the batch maximum back (one word, one stream synchronisation) unless
+  // the caller opted out with PH_FLAG_NOSYNC and checks `status` / `counts` itself.
+  if (!(flags & PH_FLAG_DEVICE) || !(flags & PH_FLAG_NOSYNC)) {
     int worst = 0;
-    for (int64_t w = 0; w < W; ++w) worst = std::max(worst, counts[w]);
+    PH_HIP(hipMemcpyAsync(&worst, dmax, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PH_HIP(hipStreamSynchronize(c->stream));
     if (worst > cap) return fail(PH_E_CAP, "a window accepted %d periods, cap is %d", worst, cap);
   }
   return PH_OK;
@@ -1152,21 +1203,9 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   if (kcap < 1 || kcap > 2048) return fail(PH_E_ARG, "kcap=%d must be in [1, 2048]", kcap);
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  size_t lds = carve_bytes(N + kPad, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
-               carve_bytes(kMaxWaves, 4) + 2 * carve_bytes(ph::kQoMaxBlocks, 4) +
-               carve_bytes(ph::kQoMaxBlocks + 1, 4) + carve_bytes(ph::kQoMaxBlocks, 8) +
-               carve_bytes((max_length + 32) / 32, 4) + carve_bytes(kcap, 8) +
-               carve_bytes((size_t)ph::kQoTile * ph::kQoPanelMax, 8) +
-               carve_bytes((size_t)kMaxWaves * ph::kQoPanelMax, 8);
-  PH_TRY(check_lds(c, lds, N, "ph_qo_find_periods"));
-  // LDS panel of the blocked Cholesky: as wide as the remaining LDS allows (<= kQoPanelMax columns)
-  const size_t ldp = (size_t)((kcap + 1) | 1);
-  const size_t room = (size_t)c->lds_limit > lds + 64 ? (size_t)c->lds_limit - lds - 64 : 0;
-  const int nbw = (int)std::min<size_t>(ph::kQoPanelMax, room / (ldp * 8));
-  if (nbw < 1)
-    return fail(PH_E_ARG, "ph_qo_find_periods: N=%d and kcap=%d leave no LDS for a Cholesky panel (limit %d B)", N,
-                kcap, c->lds_limit);
-  lds += carve_bytes(ldp * nbw, 8);
+  size_t lds;
+  int nbw;
+  PH_TRY(qo_lds_layout(c, sz, N, max_length, kcap, &lds, &nbw));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, max_length, &geom));
   const ph::PassPlan* plan;
@@ -1224,6 +1263,17 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   }
   PH_TRY(launch_check("k_qo_find"));
   return st.finish();
+}
+
+int ph_qo_feasible(ph_ctx* c, int dtype, int N, int max_length, int kcap, int* ok) {
+  if (!c || !ok) return fail(PH_E_ARG, "NULL argument");
+  *ok = 0;
+  if (N < 1 || kcap < 1 || kcap > 2048) return PH_OK;
+  if (max_length < 0) max_length = N / 3;
+  size_t lds;
+  int nbw;
+  if (qo_lds_layout(c, elem_size(dtype), N, max_length, kcap, &lds, &nbw) == PH_OK) *ok = 1;
+  return PH_OK;
 }
 
 // ----------------------------------------------------------------------------- orthogonal period powers

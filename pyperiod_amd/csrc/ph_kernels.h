@@ -507,7 +507,8 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
                                                            T* gwin, int cap, int* __restrict__ counts,
                                                            int* __restrict__ periods_out,
                                                            double* __restrict__ powers_out,
-                                                           T* __restrict__ bases_out, int* __restrict__ status_out) {
+                                                           T* __restrict__ bases_out, int* __restrict__ status_out,
+                                                           int* __restrict__ max_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* work = window_buf<T, LW>(cv, gwin, N + kPad);
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   if (tid == 0) {
     counts[w] = count;
     status_out[w] = count > cap ? 3 : 0;
+    if (count > cap) atomicMax(max_count, count);  // rare: the host retries with this capacity
   }
 }
 

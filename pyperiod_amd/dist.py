@@ -2,9 +2,18 @@
 (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 Signal windows are independent units -- no algorithm on this path exchanges data between
-windows -- so the only collectives are the optional scatter of the input batch from a root
-rank and the gather of the fixed-shape results back to it.  There is no all-reduce anywhere.
-Ragged results (small_to_large) travel as fixed (W, cap) slabs plus a count per window.
+windows -- so the only collectives are the scatter of the input batch from a root rank and the
+gather of the fixed-shape results back to it.  There is no all-reduce anywhere.  Ragged results
+(small_to_large) travel as fixed (W, cap) slabs plus a count per window.
+
+Partition: contiguous blocks of ceil(total / world) windows per rank; trailing ranks
+may get a short or an EMPTY block (total=5, world=4 -> 2, 2, 1, 0) and still take part in every
+collective -- the engine returns empty outputs for an empty batch.
+
+`run_sharded_pipelined` cuts every rank's block into pieces and scatters piece k+1 while piece k
+is being processed: the root's xGMI links (7 x ~153 GB/s, point to point) carry 7/8 of the batch,
+which for config 4 (2 GiB in, ~10 ms of compute per GPU) costs as much as the compute itself
+unless the two overlap.
 """
 
 from __future__ import annotations
@@ -28,6 +37,18 @@ def _world(group=None):
     return 1, 0
 
 
+def _rows(x_root: torch.Tensor, lo: int, count: int, total: int) -> torch.Tensor:
+    """Rows [lo, lo+count) of the root batch, zero-padded past `total` (only the pieces that
+    straddle the end of the batch are copied; the others are views)."""
+    hi = min(total, lo + count)
+    if hi - lo == count:
+        return x_root[lo:hi]
+    out = torch.zeros((count,) + tuple(x_root.shape[1:]), dtype=x_root.dtype, device=x_root.device)
+    if hi > lo:
+        out[: hi - lo] = x_root[lo:hi]
+    return out
+
+
 def scatter_windows(x_root, total: int, n: int, dtype, device, src: int = 0, group=None) -> torch.Tensor:
     """Rank `src` holds the (total, n) batch; every rank returns its own (hi-lo, n) block on
     `device`.  One scatter of equal ceil(total/world)-row chunks (the tail chunk is padded)."""
@@ -40,10 +61,7 @@ def scatter_windows(x_root, total: int, n: int, dtype, device, src: int = 0, gro
     chunks = None
     if rank == src:
         xr = x_root.to(device)
-        if xr.shape[0] < per * world:
-            pad = torch.zeros((per * world - xr.shape[0], n), dtype=dtype, device=device)
-            xr = torch.cat([xr, pad], 0)
-        chunks = [xr[r * per : (r + 1) * per].contiguous() for r in range(world)]
+        chunks = [_rows(xr, r * per, per, total).contiguous() for r in range(world)]
     dist.scatter(recv, chunks, src=src, group=group)
     return recv[: hi - lo]
 
@@ -70,10 +88,47 @@ def gather_rows(local: torch.Tensor, total: int, dst: int = 0, group=None):
 def run_sharded(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, total: int, n: int, dtype, device,
                 root: int = 0, group=None):
     """scatter -> fn(local windows) -> gather.  `fn` returns a tuple of tensors whose first
-    axis is the local window axis (e.g. ``lambda x: engine.m_best(x, 10)``).  Rank `root`
-    gets the tuple of gathered (total, ...) tensors; other ranks get None."""
+    axis is the local window axis and whose trailing shape does not depend on the data (e.g.
+    ``lambda x: engine.m_best(x, 10)``); it is also called for an empty block and must return
+    (0, ...) tensors then (every engine method does).  Rank `root` gets the tuple of gathered
+    (total, ...) tensors; other ranks get None."""
     x_local = scatter_windows(x_root, total, n, dtype, device, root, group)
     outs = fn(x_local)
     gathered = [gather_rows(o, total, root, group) for o in outs]
     _, rank = _world(group)
+    return tuple(gathered) if rank == root else None
+
+
+def run_sharded_pipelined(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, total: int, n: int, dtype,
+                          device, pieces: int = 4, root: int = 0, group=None):
+    """Like run_sharded, with the scatter cut into `pieces` asynchronous collectives per rank: all
+    of them are enqueued up front (RCCL runs them on its own stream, in order), and `fn` runs on
+    piece k as soon as it has landed while the later pieces are still in flight.  Results are
+    concatenated per rank and gathered once per output tensor."""
+    world, rank = _world(group)
+    lo, hi = shard_bounds(total, world, rank)
+    if world == 1:
+        return tuple(fn(x_root.to(device)))
+    per = -(-total // world)
+    pieces = max(1, min(int(pieces), per))
+    step = -(-per // pieces)
+    xr = x_root.to(device) if rank == root else None
+    recv, works = [], []
+    for k in range(pieces):
+        rows = min(step, per - k * step)
+        if rows <= 0:
+            break
+        buf = torch.empty((rows, n), dtype=dtype, device=device)
+        lists = None
+        if rank == root:
+            lists = [_rows(xr, r * per + k * step, rows, total).contiguous() for r in range(world)]
+        works.append(dist.scatter(buf, lists, src=root, group=group, async_op=True))
+        recv.append(buf)
+    outs = []
+    for k, (buf, work) in enumerate(zip(recv, works)):
+        work.wait()  # orders the current stream behind this piece only
+        valid = max(0, min(hi - lo - k * step, buf.shape[0]))
+        outs.append(fn(buf[:valid]))
+    merged = [torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))]
+    gathered = [gather_rows(o, total, root, group) for o in merged]
     return tuple(gathered) if rank == root else None

@@ -33,6 +33,7 @@ class _Out:
 
     def __init__(self, like):
         self.torch = _is_torch(like)
+        self.stream = None  # hipStream_t handle the call must run on (None = the context's own)
         if self.torch:
             import torch
 
@@ -112,22 +113,35 @@ class PeriodEngine:
             code = {torch.float64: _ffi.PH_F64, torch.float32: _ffi.PH_F32}.get(x.dtype)
             if code is None:
                 raise TypeError(f"unsupported dtype {x.dtype}")
+            mk = _Out(x)
             # torch's default stream has the handle 0 (== NULL, "own stream" in the C ABI)
-            stream = torch.cuda.current_stream(x.device).cuda_stream or _ffi.PH_STREAM_DEFAULT
-            if stream != self._bound_stream:
-                _ffi.check(self._lib.ph_set_stream(self._ctx, C.c_void_p(stream)))
-                self._bound_stream = stream
-            return x, code, x.shape[0], x.shape[1], _ffi.PH_FLAG_DEVICE, _Out(x)
+            mk.stream = torch.cuda.current_stream(x.device).cuda_stream or _ffi.PH_STREAM_DEFAULT
+            return x, code, x.shape[0], x.shape[1], _ffi.PH_FLAG_DEVICE, mk
         x = np.asarray(x)
         if x.ndim != 2:
             raise ValueError("expected a (W, N) batch of windows")
         if x.dtype not in _NP_DTYPES:
             x = x.astype(np.float64)
         x = np.ascontiguousarray(x)
-        if self._bound_stream is not None:
-            _ffi.check(self._lib.ph_set_stream(self._ctx, None))
-            self._bound_stream = None
         return x, _NP_DTYPES[x.dtype], x.shape[0], x.shape[1], 0, _Out(x)
+
+    def _call(self, mk, W, fn, *args, check=True):
+        """One library call under the engine lock: the context is bound to the caller's stream
+        (torch's current stream for device tensors, the context's own stream for numpy) and the
+        entry point is invoked while the lock is held, so threads sharing an engine cannot launch
+        on each other's stream.  An empty batch (W == 0, e.g. a trailing rank of a sharded run)
+        makes no call: the outputs are already empty."""
+        if W == 0:
+            return _ffi.PH_OK
+        with self._lock:
+            want = mk.stream
+            if want != self._bound_stream:
+                _ffi.check(self._lib.ph_set_stream(self._ctx, C.c_void_p(want) if want else None))
+                self._bound_stream = want
+            rc = fn(self._ctx, *args)
+        if check:
+            _ffi.check(rc)
+        return rc
 
     @staticmethod
     def _np_dtype(code):
@@ -176,8 +190,7 @@ class PeriodEngine:
     def periodic_norm(self, x, p=None):
         x, code, W, N, fl, mk = self._prep(x)
         out = mk.empty((W,), np.float64)
-        with self._lock:
-            _ffi.check(self._lib.ph_periodic_norm(self._ctx, mk.addr(x), code, W, N, int(p) if p else 0, fl, mk.addr(out)))
+        self._call(mk, W, self._lib.ph_periodic_norm, mk.addr(x), code, W, N, int(p) if p else 0, fl, mk.addr(out))
         return out
 
     def project_batch(self, x, p_list, trunc=False, orth=False, single=False):
@@ -189,10 +202,8 @@ class PeriodEngine:
         keep = self._orth(orth, pl.max())
         out = mk.empty((W, pl.size, N), self._np_dtype(code))
         flags = fl | self._flags(trunc, orth) | (_ffi.PH_FLAG_SINGLE if single else 0)
-        with self._lock:
-            _ffi.check(
-                self._lib.ph_project_batch(self._ctx, mk.addr(x), code, W, N, pl_addr, pl.size, keep[2], keep[3], keep[4], flags, mk.addr(out))
-            )
+        self._call(mk, W, self._lib.ph_project_batch, mk.addr(x), code, W, N, pl_addr, pl.size, keep[2], keep[3], keep[4],
+                   flags, mk.addr(out))
         return out
 
     def sweep(self, x, p_lo, p_hi, mode=_ffi.PH_SWEEP_NORM, trunc=False, orth=False):
@@ -200,11 +211,16 @@ class PeriodEngine:
         x, code, W, N, fl, mk = self._prep(x)
         keep = self._orth(orth and mode != _ffi.PH_SWEEP_MAXABS, p_hi)
         out = mk.empty((W, int(p_hi) - int(p_lo) + 1), np.float64)
-        with self._lock:
-            _ffi.check(
-                self._lib.ph_sweep(self._ctx, mk.addr(x), code, W, N, int(p_lo), int(p_hi), int(mode), keep[2], keep[3], keep[4], fl | self._flags(trunc, orth), mk.addr(out))
-            )
+        self._call(mk, W, self._lib.ph_sweep, mk.addr(x), code, W, N, int(p_lo), int(p_hi), int(mode), keep[2], keep[3],
+                   keep[4], fl | self._flags(trunc, orth), mk.addr(out))
         return out
+
+    def sweep_plan_info(self, p_lo, p_hi):
+        """Pass plan of the norm sweeps over [p_lo, p_hi]: (passes, periods) -- every pass reads the
+        LDS-resident window once and yields one to three candidate periods."""
+        n_pass, n_per = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.ph_sweep_plan_info(self._ctx, int(p_lo), int(p_hi), C.byref(n_pass), C.byref(n_per)))
+        return n_pass.value, n_per.value
 
     def m_best(self, x, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False, want_sweeps=False):
         """-> periods (W,num) uint32, powers (W,num) f64, bases (W,num,N), status (W) int32
@@ -220,40 +236,38 @@ class PeriodEngine:
         bases = mk.empty((W, num, N), self._np_dtype(code))
         status = mk.empty((W,), np.int32)
         sweeps = mk.empty((W,), np.int32) if want_sweeps else None
-        with self._lock:
-            _ffi.check(
-                self._lib.ph_m_best(
-                    self._ctx, mk.addr(x), code, W, N, num, min_length, max_length, 1 if gamma else 0,
-                    keep[2], keep[3], foff.ctypes.data, fq.ctypes.data, max(max_length, 1),
-                    fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status),
-                    mk.addr(sweeps),
-                )
-            )
+        self._call(mk, W, self._lib.ph_m_best, mk.addr(x), code, W, N, num, min_length, max_length, 1 if gamma else 0,
+                   keep[2], keep[3], foff.ctypes.data, fq.ctypes.data, max(max_length, 1),
+                   fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status),
+                   mk.addr(sweeps))
         if want_sweeps:
             return periods, powers, bases, status, sweeps
         return periods, powers, bases, status
 
-    def small_to_large(self, x, thresh=0.1, n_periods=None, trunc=False, orth=False, cap=16, want_bases=True):
+    def small_to_large(self, x, thresh=0.1, n_periods=None, trunc=False, orth=False, cap=16, want_bases=True,
+                       nosync=False):
         """-> counts (W), periods (W,cap) int32, powers (W,cap), bases (W,cap,N)|None, status (W).
-        Host-pointer calls grow `cap` and retry when a window accepts more periods."""
+        A window that accepts more than `cap` periods makes the library return PH_E_CAP -- for
+        numpy and for device tensors alike (the library reads one device word back) -- and the
+        call is repeated with the capacity the batch needs.  nosync=True (device tensors only)
+        skips that read-back: the call stays asynchronous and the caller must look at `status`
+        (PH_ST_CAP) / `counts` itself."""
         x, code, W, N, fl, mk = self._prep(x)
         if n_periods is None:
             n_periods = N // 2
         n_periods = int(n_periods)
         keep = self._orth(orth, max(n_periods, 1))
+        fl |= _ffi.PH_FLAG_NOSYNC if (nosync and mk.torch) else 0
         while True:
             counts = mk.empty((W,), np.int32)
             periods = mk.empty((W, cap), np.int32)
             powers = mk.empty((W, cap), np.float64)
             bases = mk.empty((W, cap, N), self._np_dtype(code)) if want_bases else None
             status = mk.empty((W,), np.int32)
-            with self._lock:
-                rc = self._lib.ph_small_to_large(
-                    self._ctx, mk.addr(x), code, W, N, float(thresh), n_periods, keep[2], keep[3], keep[4],
-                    fl | self._flags(trunc, orth), int(cap), mk.addr(counts), mk.addr(periods), mk.addr(powers),
-                    mk.addr(bases), mk.addr(status),
-                )
-            if rc == _ffi.PH_E_CAP and not mk.torch:
+            rc = self._call(mk, W, self._lib.ph_small_to_large, mk.addr(x), code, W, N, float(thresh), n_periods,
+                            keep[2], keep[3], keep[4], fl | self._flags(trunc, orth), int(cap), mk.addr(counts),
+                            mk.addr(periods), mk.addr(powers), mk.addr(bases), mk.addr(status), check=False)
+            if rc == _ffi.PH_E_CAP:
                 cap = int(counts.max())
                 continue
             _ffi.check(rc)
@@ -269,13 +283,9 @@ class PeriodEngine:
         norms = mk.empty((W, num), np.float64)
         bases = mk.empty((W, num, N), self._np_dtype(code))
         status = mk.empty((W,), np.int32)
-        with self._lock:
-            _ffi.check(
-                self._lib.ph_best_correlation(
-                    self._ctx, mk.addr(x), code, W, N, num, max_length, float(ratio), keep[2], keep[3], keep[4],
-                    fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(norms), mk.addr(bases), mk.addr(status),
-                )
-            )
+        self._call(mk, W, self._lib.ph_best_correlation, mk.addr(x), code, W, N, num, max_length, float(ratio), keep[2],
+                   keep[3], keep[4], fl | self._flags(trunc, orth), mk.addr(periods), mk.addr(norms), mk.addr(bases),
+                   mk.addr(status))
         return periods, norms, bases, status
 
     def best_frequency(self, x, win_size=None, num=5, trunc=False, orth=False):
@@ -289,16 +299,11 @@ class PeriodEngine:
         powers = mk.empty((W, num), np.float64)
         bases = mk.empty((W, num, N), self._np_dtype(code))
         status = mk.empty((W,), np.int32)
-        with self._lock:
-            for w0 in range(0, W, 65535):  # the spectrum kernel's grid.y holds the window index
-                w1 = min(W, w0 + 65535)
-                _ffi.check(
-                    self._lib.ph_best_frequency(
-                        self._ctx, mk.addr(x[w0:w1]), code, w1 - w0, N, win_size, num, keep[2], keep[3], keep[4],
-                        fl | self._flags(trunc, orth), mk.addr(periods[w0:w1]), mk.addr(powers[w0:w1]),
-                        mk.addr(bases[w0:w1]), mk.addr(status[w0:w1]),
-                    )
-                )
+        for w0 in range(0, W, 65535):  # the spectrum kernel's grid.y holds the window index
+            w1 = min(W, w0 + 65535)
+            self._call(mk, w1 - w0, self._lib.ph_best_frequency, mk.addr(x[w0:w1]), code, w1 - w0, N, win_size, num,
+                       keep[2], keep[3], keep[4], fl | self._flags(trunc, orth), mk.addr(periods[w0:w1]),
+                       mk.addr(powers[w0:w1]), mk.addr(bases[w0:w1]), mk.addr(status[w0:w1]))
         return periods, powers, bases, status
 
     def ramanujan_norms(self, x, q_lo=2, q_hi=None):
@@ -307,8 +312,7 @@ class PeriodEngine:
         if not q_hi:
             q_hi = N // 3
         out = mk.empty((W, int(q_hi) + 1), np.float64)
-        with self._lock:
-            _ffi.check(self._lib.ph_ramanujan_norms(self._ctx, mk.addr(x), code, W, N, int(q_lo), int(q_hi), fl, mk.addr(out)))
+        self._call(mk, W, self._lib.ph_ramanujan_norms, mk.addr(x), code, W, N, int(q_lo), int(q_hi), fl, mk.addr(out))
         return out
 
     def dict_project(self, x, basis):
@@ -318,11 +322,8 @@ class PeriodEngine:
         if x.ndim != 1 or basis.ndim != 2 or basis.shape[1] != x.size:
             raise ValueError("x must be (N,) and basis (rows, N)")
         out = np.empty(basis.shape, dtype=np.float32)
-        with self._lock:
-            if self._bound_stream is not None:
-                _ffi.check(self._lib.ph_set_stream(self._ctx, None))
-                self._bound_stream = None
-            _ffi.check(self._lib.ph_dict_project(self._ctx, x.ctypes.data, basis.ctypes.data, basis.shape[0], x.size, 0, out.ctypes.data))
+        self._call(_Out(x), basis.shape[0], self._lib.ph_dict_project, x.ctypes.data, basis.ctypes.data, basis.shape[0],
+                   x.size, 0, out.ctypes.data)
         return out
 
     def qo_find_periods(self, x, num, thresh, min_length=2, max_length=None, kcap=512):
@@ -340,15 +341,19 @@ class PeriodEngine:
         weights = mk.empty((W, int(kcap)), np.float64)
         resid = mk.empty((W, N), self._np_dtype(code))
         status = mk.empty((W,), np.int32)
-        with self._lock:
-            _ffi.check(
-                self._lib.ph_qo_find_periods(
-                    self._ctx, mk.addr(x), code, W, N, num, float(thresh), int(min_length), int(max_length), int(kcap),
-                    fl, mk.addr(periods), mk.addr(norms), mk.addr(keeps), mk.addr(counts), mk.addr(weights),
-                    mk.addr(resid), mk.addr(status),
-                )
-            )
+        self._call(mk, W, self._lib.ph_qo_find_periods, mk.addr(x), code, W, N, num, float(thresh), int(min_length),
+                   int(max_length), int(kcap), fl, mk.addr(periods), mk.addr(norms), mk.addr(keeps), mk.addr(counts),
+                   mk.addr(weights), mk.addr(resid), mk.addr(status))
         return periods, norms, keeps, counts, weights, resid, status
+
+    def qo_feasible(self, n, dtype=np.float64, kcap=512, max_length=None) -> bool:
+        """Whether ph_qo_find_periods can run a window of n samples with `kcap` dictionary rows
+        (window + solve vector + one Cholesky panel column must fit the workgroup's LDS)."""
+        ok = C.c_int(0)
+        code = _NP_DTYPES[np.dtype(dtype)]
+        _ffi.check(self._lib.ph_qo_feasible(self._ctx, code, int(n), int(max_length if max_length is not None else n // 3),
+                                            int(kcap), C.byref(ok)))
+        return bool(ok.value)
 
     def orth_powers(self, x, max_p=None, normalize=False, want_autocorr=False, want_eq3=False):
         """Orthogonal period powers (QOPeriods.get_best_period_orthogonal(return_powers=True)).
@@ -360,11 +365,8 @@ class PeriodEngine:
         pows = mk.empty((W, max_p), np.float64)
         ac = mk.empty((W, N), np.float64) if want_autocorr else None
         e3 = mk.empty((W, max_p), np.float64) if want_eq3 else None
-        with self._lock:
-            _ffi.check(
-                self._lib.ph_orth_powers(self._ctx, mk.addr(x), code, W, N, max_p, 1 if normalize else 0, fl,
-                                         mk.addr(ac), mk.addr(e3), mk.addr(pows))
-            )
+        self._call(mk, W, self._lib.ph_orth_powers, mk.addr(x), code, W, N, max_p, 1 if normalize else 0, fl,
+                   mk.addr(ac), mk.addr(e3), mk.addr(pows))
         out = (pows,)
         if want_autocorr:
             out += (ac,)
@@ -378,8 +380,7 @@ class PeriodEngine:
         pl, pl_addr = _i32(np.atleast_1d(p_list))
         kp, kp_addr = _i32(np.atleast_1d(keep))
         out = mk.empty((W, int(kp.sum())), np.float64)
-        with self._lock:
-            _ffi.check(self._lib.ph_fold_sums(self._ctx, mk.addr(x), code, W, N, pl_addr, kp_addr, pl.size, fl, mk.addr(out)))
+        self._call(mk, W, self._lib.ph_fold_sums, mk.addr(x), code, W, N, pl_addr, kp_addr, pl.size, fl, mk.addr(out))
         return out
 
     def tile_sum(self, wts, n, p_list, keep, dtype=np.float64):
@@ -393,8 +394,7 @@ class PeriodEngine:
             raise ValueError("weights row length must equal sum(keep)")
         ocode = _NP_DTYPES[np.dtype(dtype)]
         out = mk.empty((W, int(n)), self._np_dtype(ocode))
-        with self._lock:
-            _ffi.check(self._lib.ph_tile_sum(self._ctx, mk.addr(wts2), W, int(n), pl_addr, kp_addr, pl.size, ocode, fl, mk.addr(out)))
+        self._call(mk, W, self._lib.ph_tile_sum, mk.addr(wts2), W, int(n), pl_addr, kp_addr, pl.size, ocode, fl, mk.addr(out))
         return out
 
 

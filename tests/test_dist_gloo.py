@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pyperiod_amd.dist import gather_rows, run_sharded, scatter_windows, shard_bounds
+from pyperiod_amd.dist import gather_rows, run_sharded, run_sharded_pipelined, scatter_windows, shard_bounds
 
 
 def _free_port():
@@ -53,30 +53,45 @@ def _worker(rank, world, port, total, n, q):
                 p, w, _ = po.m_best(row, 3)
                 per.append(p.astype(np.int64))
                 pw.append(w)
-            return torch.from_numpy(np.array(per)), torch.from_numpy(np.array(pw))
+            # an empty block (trailing rank) yields (0, 3) results, like the engine does
+            return (torch.from_numpy(np.array(per, dtype=np.int64).reshape(-1, 3)),
+                    torch.from_numpy(np.array(pw, dtype=np.float64).reshape(-1, 3)))
 
-        res = run_sharded(compute, x_root, total, n, torch.float64, torch.device("cpu"))
+        want = [po.m_best(row, 3) for row in multi_sinusoid_batch(0, total, n)] if rank == 0 else None
+        for runner in (run_sharded, lambda *a: run_sharded_pipelined(*a, pieces=2)):
+            res = runner(compute, x_root, total, n, torch.float64, torch.device("cpu"))
+            if rank == 0:
+                per, pw = res
+                assert per.shape == (total, 3)
+                assert np.array_equal(per.numpy(), np.array([w[0] for w in want]))
+                assert np.allclose(pw.numpy(), np.array([w[1] for w in want]), rtol=1e-12)
+            else:
+                assert res is None
         if rank == 0:
-            per, pw = res
-            want = [po.m_best(row, 3) for row in multi_sinusoid_batch(0, total, n)]
-            assert np.array_equal(per.numpy(), np.array([w[0] for w in want]))
-            assert np.allclose(pw.numpy(), np.array([w[1] for w in want]), rtol=1e-12)
             q.put("ok")
-        else:
-            assert res is None
     finally:
         dist.destroy_process_group()
 
 
-def test_scatter_compute_gather_world2():
-    total, n = 5, 256  # odd count: the last rank's block is shorter
+def _launch(world, total, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+def test_scatter_compute_gather_world2():
+    _launch(2, 5, 256)  # odd count: the last rank's block is shorter
+
+
+def test_empty_trailing_shard_world4():
+    """total=5 over 4 ranks -> blocks of 2, 2, 1, 0 windows: the rank with the empty block must
+    still take part in every collective (it used to raise before the gather and hang its peers)."""
+    assert shard_bounds(5, 4, 3) == (5, 5)
+    _launch(4, 5, 192)

@@ -7,7 +7,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import elem_err, rel_err
 from oracle import period_oracle as po
 from pyperiod_amd.synth import multi_sinusoid_window, readme_window
 
@@ -234,3 +234,68 @@ def test_orthogonal_period_powers(golden):
     assert rel_err([po.eq_3(sig, q) for q in range(1, 60)], g["eq3_w1_n600"]) < 1e-12
     assert rel_err([po.auto_corr(sig, k) for k in range(0, 600, 7)], g["autocorr_w1_n600"]) < 1e-13
 
+
+
+# ---------------------------------------------------------------------------------- round-2 fixtures
+@pytest.mark.parametrize("name,gamma", [("m_best_gamma", True), ("m_best", False)])
+def test_m_best_step2_splits(golden, name, gamma):
+    """Calls in which step 2 really splits a row (np.insert fires, Periods.py:581-594); in gamma mode
+    this pins the stale-`p` divisor of Periods.py:559,572."""
+    g = golden("m_best_split")
+    for n, ml, num, w in g["cases"]:
+        tag = f"{name}_n{n}_ml{ml}_num{num}_w{w}"
+        if gamma:
+            assert int(g[tag + "_splits"]) >= 1
+        per, pw, bs = po.m_best(multi_sinusoid_window(int(w), int(n)), int(num), int(ml), 2, gamma)
+        assert np.array_equal(per, g[tag + "_periods"]), tag
+        assert rel_err(pw, g[tag + "_powers"]) < TOL and elem_err(pw, g[tag + "_powers"]) < 1e-9
+        assert rel_err(bs, g[tag + "_bases"]) < TOL
+
+
+def test_ramanujan_config3_shape(golden):
+    """N = 8192, q = 2..512 (BASELINE config 3): the fp64 folded form against the float32 reference."""
+    g = golden("ramanujan_c3")
+    for w in (0, 1):
+        want = g[f"norms_n8192_pmax512_w{w}"]
+        got = po.ramanujan_norms_folded(multi_sinusoid_window(w, 8192), 2, 512)
+        assert want.shape == (513,) and rel_err(got, want) < 1e-5
+        assert elem_err(got, want, 1e-4) < 1e-4  # weak subspaces sit in the reference's float32 noise
+
+
+def test_ramanujan_find_periods_with_weights(golden):
+    g = golden("ramanujan_weights")
+    for tag, sig, kw in (
+        ("n240", multi_sinusoid_window(0, 240), dict(min_length=2, max_length=80, thresh=0.2)),
+        ("n1000", multi_sinusoid_window(2, 1000), dict(thresh=0.3)),
+        ("n600", multi_sinusoid_window(5, 600), dict(min_length=3, max_length=150, thresh=0.1)),
+    ):
+        out, res = po.ramanujan_find_periods_with_weights(sig, **kw)
+        assert np.array_equal(out["periods"], g[f"{tag}_periods"]), tag
+        assert rel_err(out["norms"], g[f"{tag}_norms"]) < 1e-5
+        assert [int(k) for k in out["basis_dictionary"]] == list(g[f"{tag}_dict_keys"])
+        assert list(out["basis_dictionary"].values()) == list(g[f"{tag}_dict_vals"])
+        assert rel_err(out["weights"], g[f"{tag}_weights"]) < 1e-8 and rel_err(res, g[f"{tag}_residual"]) < 1e-8
+
+
+def test_qoperiods_config5_length(golden):
+    """QOPeriods.find_periods on fp32-rounded windows of N = 16384 (config 5's length)."""
+    g = golden("qoperiods_c5")
+    for tag, w, kw in (
+        ("w0", 0, dict(num=3, thresh=0.1, min_length=8, max_length=300)),
+        ("w7", 7, dict(num=4, thresh=0.05, min_length=8, max_length=300)),
+    ):
+        sig = multi_sinusoid_window(w, 16384, dtype=np.float32).astype(np.float64)
+        out, res = po.qo_find_periods(sig, **kw)
+        assert np.array_equal(out["periods"], g[f"fp_{tag}_periods"]), tag
+        assert rel_err(out["norms"], g[f"fp_{tag}_norms"]) < TOL
+        assert list(out["basis_dictionary"].values()) == list(g[f"fp_{tag}_dict_vals"])
+        assert rel_err(out["weights"], g[f"fp_{tag}_weights"]) < 1e-7
+        assert rel_err(res, g[f"fp_{tag}_residual"]) < 1e-6  # the fixture stores the residual as float32
+
+
+def test_elementwise_bar_on_sweeps(golden):
+    """north_star's 1e-10 is a relative bar: hold the oracle to it entry by entry."""
+    g = golden("sweep")
+    x = multi_sinusoid_window(0, 4096)
+    assert elem_err(po.sweep_norms(x, 2, 4096 // 3), g["plain_w0"]) < 1e-12
+    assert elem_err(po.sweep_norms(x, 2, 4096 // 3, gamma=True), g["gamma_w0"]) < 1e-12
