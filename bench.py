@@ -92,7 +92,7 @@ def cpu_baseline(n, num, per_worker=8):
         avail = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
-    cores = max(1, avail)
+    cores = max(1, min(avail, 16))  # a one-GPU box owns a 16-core share of its host, whatever cpu_count says
     ctx = mp.get_context("spawn")
     jobs = [(i * per_worker, per_worker, n, num) for i in range(cores)]
     t0 = time.perf_counter()
@@ -106,6 +106,7 @@ def cpu_baseline(n, num, per_worker=8):
         "unit": "window-projections/s",
         "cores": cores,
         "os_cpu_count": os.cpu_count(),
+        "affinity_cpus": avail,
         "kind": "port",
         "sample": f"oracle m_best(num={num}) on windows 0..{cores * per_worker - 1} (N={n}), "
         f"{per_worker} per core on {cores} cores, {projections} projections, {busy:.1f} s busy / {wall:.1f} s wall",
@@ -132,7 +133,7 @@ def synth_windows(total, n, procs=None):
             procs = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             procs = os.cpu_count() or 1
-        procs = max(1, min(procs, 32))
+        procs = max(1, min(procs, 16))
     out = np.empty((total, n), dtype=np.float64)
     chunk = 1024
     jobs = [(w0, min(chunk, total - w0), n) for w0 in range(0, total, chunk)]

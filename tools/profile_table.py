@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Build the per-kernel evidence table from one tools/profile_all.sh capture:
+  profile_table.py <dir with kernel_stats.csv, pmc_summary.csv, hip_events.json> [--md]
+Columns: rocprofv3 average duration, HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, KiB counters;
+FETCH_SIZE doubled per MI355X_MICROARCH.md), LDS-array utilisation SQ_LDS_IDX_ACTIVE / CU-cycles
+(CU-cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs x 32 CUs per XCD), VALU / SALU / LDS instruction
+counts.  Also shortens the kernel names of kernel_stats.csv (kernel_stats_short.csv)."""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+d = sys.argv[1]
+md = "--md" in sys.argv
+
+
+def short(name):
+    m = re.search(r"ph::(k_[a-z0-9_]+)(<[^>(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else None
+
+
+dur = {}
+rows = []
+with open(os.path.join(d, "kernel_stats.csv")) as fh:
+    for r in csv.DictReader(fh):
+        s = short(r["Name"])
+        if s:
+            dur[s] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
+            rows.append((s, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
+with open(os.path.join(d, "kernel_stats_short.csv"), "w") as fh:
+    fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+    for r in rows:
+        fh.write(",".join(str(v) for v in r) + "\n")
+pmc = collections.defaultdict(dict)
+for line in open(os.path.join(d, "pmc_summary.csv")):
+    k, c, n, v = line.strip().rsplit(",", 3)
+    pmc[short(k) or k][c] = float(v)
+hdr = ["kernel", "calls", "avg_ms", "hbm_MB_per_launch", "hbm_GBs", "hbm_frac_8TBs", "lds_array_util", "valu_insts", "salu_insts", "lds_insts", "wait_frac"]
+out = []
+traffic = {}
+for k in sorted(dur, key=lambda k: -dur[k][1] * dur[k][0]):
+    c = pmc.get(k, {})
+    calls, ms = dur[k]
+    hbm = (2 * c.get("FETCH_SIZE", float("nan")) + c.get("WRITE_SIZE", float("nan"))) * 1024
+    cu_cycles = c.get("GRBM_GUI_ACTIVE", float("nan")) * 32
+    util = c.get("SQ_LDS_IDX_ACTIVE", float("nan")) / cu_cycles if cu_cycles else float("nan")
+    wait = c.get("SQ_WAIT_ANY", float("nan")) / c.get("SQ_WAVE_CYCLES", float("nan")) if c.get("SQ_WAVE_CYCLES") else float("nan")
+    out.append([k, calls, "%.4f" % ms, "%.2f" % (hbm / 1e6), "%.0f" % (hbm / (ms * 1e-3) / 1e9), "%.3f" % (hbm / (ms * 1e-3) / 8e12),
+                "%.3f" % util, "%.3g" % c.get("SQ_INSTS_VALU", float("nan")), "%.3g" % c.get("SQ_INSTS_SALU", float("nan")),
+                "%.3g" % c.get("SQ_INSTS_LDS", float("nan")), "%.2f" % wait])
+    traffic[k.split("<")[0]] = {"kernel": k, "hbm_bytes_per_launch": hbm, "fetch_size_kib": c.get("FETCH_SIZE"), "write_size_kib": c.get("WRITE_SIZE"),
+                                 "avg_ms_rocprof": ms}
+if md:
+    print("| " + " | ".join(hdr) + " |")
+    print("|" + "---|" * len(hdr))
+    for r in out:
+        print("| " + " | ".join(str(v) for v in r) + " |")
+else:
+    print(",".join(hdr))
+    for r in out:
+        print(",".join(str(v) for v in r))
+with open(os.path.join(d, "traffic.json"), "w") as fh:
+    json.dump(traffic, fh, indent=1)
