@@ -387,21 +387,27 @@ def ramanujan_find_periods(x, min_length=2, max_length=None) -> np.ndarray:
     return norms
 
 
+def ramanujan_norm_folded_q(x, q: int) -> float:
+    """One entry of the folded form below: a = S_q (star) c_q / phi(q), o = a (*) c_q / phi(q),
+    norms[q] = sum_j cnt_q[j] o_j^2."""
+    q = int(q)
+    c = ramanujan_cq_exact(q).astype(np.float64) / phi(q)
+    s = fold_sums(x, q)
+    idx = (np.arange(q)[None, :] - np.arange(q)[:, None]) % q  # idx[i, j] = (j - i) mod q
+    a = (c[idx] * s[None, :]).sum(1)  # a_i = sum_j S[j] c((j-i) mod q)
+    o = (c[idx] * a[:, None]).sum(0)  # o_j = sum_i a_i c((j-i) mod q)
+    return float(np.sum(fold_counts(len(x), q) * o * o))
+
+
 def ramanujan_norms_folded(x, min_length=2, max_length=None) -> np.ndarray:
-    """fp64 folded form of the same quantity: a = S_q (star) c_q / phi(q),
-    o = a (*) c_q / phi(q), norms[q] = sum_j cnt_q[j] o_j^2.  This is what the HIP kernel
+    """fp64 folded form of the same quantity.  This is what the HIP kernel
     evaluates; it differs from the float32 reference path by ~1e-7 relative."""
     n = len(x)
     if not max_length:
         max_length = n // 3
     norms = np.zeros(max_length + 1)
     for q in range(min_length, max_length + 1):
-        c = ramanujan_cq_exact(q).astype(np.float64) / phi(q)
-        s = fold_sums(x, q)
-        idx = (np.arange(q)[None, :] - np.arange(q)[:, None]) % q  # idx[i, j] = (j - i) mod q
-        a = (c[idx] * s[None, :]).sum(1)  # a_i = sum_j S[j] c((j-i) mod q)
-        o = (c[idx] * a[:, None]).sum(0)  # o_j = sum_i a_i c((j-i) mod q)
-        norms[q] = np.sum(fold_counts(n, q) * o * o)
+        norms[q] = ramanujan_norm_folded_q(x, q)
     return norms
 
 

@@ -976,18 +976,32 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   if (q_lo < 1 || q_hi < 1) return fail(PH_E_ARG, "need q_lo, q_hi >= 1 (got %d, %d)", q_lo, q_hi);
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  const int nw = ph::kRamBlock / 64;
-  size_t lds = carve_bytes(N + kPad, sz) + carve_bytes((size_t)nw * q_hi, 8);
-  void* gwin;
-  PH_TRY(place_window(c, &lds, N + kPad, sz, W, &gwin));
+  // Per wavefront: strip A (q_hi doubles, the root fold) and strip B (q_hi / 2, one child).  As many
+  // wavefronts as the LDS left by the window allows, at most 16; when fewer than four fit beside an
+  // LDS-resident window (the reference's default range q_hi = N / 3 on a long window) the window moves
+  // to the HBM workspace and the strips get the whole LDS.
+  const size_t strip = carve_bytes((size_t)q_hi, 8) + carve_bytes((size_t)std::max(1, q_hi / 2), 8);
+  const size_t win_bytes = carve_bytes(N + kPad, sz);
+  auto waves_for = [&](size_t room) { return (int)std::min<size_t>(ph::kRamMaxWaves, room / strip); };
+  const size_t limit = (size_t)c->lds_limit;
+  int nw = win_bytes + 64 < limit ? waves_for(limit - win_bytes - 64) : 0;
+  void* gwin = nullptr;
+  if (nw < 4) {
+    const int nw_hbm = waves_for(limit - 64);
+    if (nw_hbm > nw) {
+      nw = nw_hbm;
+      PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * ph::win_stride(N + kPad) * sz));
+      gwin = c->buf[B_GWIN].p;
+    }
+  }
+  if (nw < 1)
+    return fail(PH_E_ARG, "ph_ramanujan_norms: q_hi=%d needs %zu B of LDS per wavefront, device limit is %d B", q_hi, strip,
+                c->lds_limit);
+  const size_t lds = (gwin ? 0 : win_bytes) + carve_bytes((size_t)nw * q_hi, 8) +
+                     carve_bytes((size_t)nw * std::max(1, q_hi / 2), 8);
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, q_hi, &geom));
-  // pass plan: multi-class passes need the whole base in registers (two-class bases <= 256,
-  // four-class bases <= 128) and rows past the window inside the zero pad (base <= 256)
-  const ph::PassPlan* plan = nullptr;
-  int n_pass = 0;
-  if (q_lo <= q_hi) PH_TRY(prepare_plan(c, q_lo, q_hi, &plan, &n_pass, q_hi <= 512 ? 4 : 1));
   // integer tables: Euler phi and, for every q, q / r for each prime r | q
   std::vector<int32_t> phi(q_hi + 1), off(q_hi + 2, 0), dd;
   {
@@ -1009,10 +1023,44 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
     off[q_hi + 1] = (int32_t)dd.size();
     if (dd.empty()) dd.push_back(1);
   }
-  const int *d_off, *d_d, *d_phi;
+  // Root plan: roots are the periods of (q_hi/2, q_hi]; every wanted q <= q_hi/2 becomes the child of one
+  // of its multiples there (the least loaded one; children cost a strip fold and a filter, O(Q + q)).
+  // Roots are dealt to the wavefronts in order of decreasing work.
+  std::vector<int32_t> tab;  // RamRoot records (4 ints each), then the children
+  int n_root = 0;
+  if (q_lo <= q_hi) {
+    const int half = q_hi / 2;
+    std::vector<std::vector<int32_t>> kids((size_t)q_hi + 1);
+    std::vector<int64_t> load((size_t)q_hi + 1, 0);
+    for (int Q = half + 1; Q <= q_hi; ++Q) load[Q] = (int64_t)N + Q;
+    for (int q = std::min(half, q_hi); q >= q_lo; --q) {
+      int best = 0;
+      for (int Q = ((half / q) + 1) * q; Q <= q_hi; Q += q)
+        if (!best || load[Q] < load[best]) best = Q;
+      kids[best].push_back(q);
+      load[best] += 2 * (int64_t)best + 4 * q;
+    }
+    std::vector<int> order;
+    for (int Q = half + 1; Q <= q_hi; ++Q)
+      if (Q >= q_lo || !kids[Q].empty()) order.push_back(Q);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
+    n_root = (int)order.size();
+    tab.resize((size_t)4 * n_root);
+    for (int i = 0; i < n_root; ++i) {
+      const int Q = order[i];
+      tab[4 * i + 0] = Q;
+      tab[4 * i + 1] = (int32_t)(tab.size() - (size_t)4 * n_root);
+      for (int q : kids[Q]) tab.push_back(q);
+      tab[4 * i + 2] = (int32_t)(tab.size() - (size_t)4 * n_root);
+      tab[4 * i + 3] = Q >= q_lo ? 1 : 0;
+    }
+  }
+  if (tab.empty()) tab.push_back(0);
+  const int *d_off, *d_d, *d_phi, *d_tab;
   PH_TRY(upload_table(c, T_AUX0, off.data(), off.size(), &d_off));
   PH_TRY(upload_table(c, T_AUX1, dd.data(), dd.size(), &d_d));
   PH_TRY(upload_table(c, T_AUX3, phi.data(), phi.size(), &d_phi));
+  PH_TRY(upload_table(c, T_AUX2, tab.data(), tab.size(), &d_tab));
   Stage st(c, flags);
   const void* dx;
   void* dout;
@@ -1020,14 +1068,17 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(st.out(B_OUT0, out, (size_t)W * (q_hi + 1) * sizeof(double), &dout));
   PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * (q_hi + 1) * sizeof(double), c->stream));
   const dim3 grid((unsigned)W);
-  if (q_lo <= q_hi) {
+  if (n_root > 0) {
+    static_assert(sizeof(ph::RamRoot) == 4 * sizeof(int32_t), "RamRoot is uploaded as four ints");
+    const ph::RamRoot* d_roots = reinterpret_cast<const ph::RamRoot*>(d_tab);
+    const int* d_child = d_tab + (size_t)4 * n_root;
     PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
       using T = decltype(t);
       auto kernel = ph::k_ramanujan<T, decltype(lw)::value>;
       PH_TRY(allow_lds(kernel, lds));
       ProfScope ps_(c, "k_ramanujan");
-      hipLaunchKernelGGL(kernel, grid, dim3(ph::kRamBlock), lds, c->stream, (const T*)dx, N, q_lo, q_hi, geom, plan,
-                         n_pass, d_off, d_d, d_phi, (T*)gwin, (double*)dout);
+      hipLaunchKernelGGL(kernel, grid, dim3(nw * 64), lds, c->stream, (const T*)dx, N, q_hi, geom, d_roots, n_root, d_child,
+                         d_off, d_d, d_phi, (T*)gwin, (double*)dout);
       return (int)PH_OK;
     }));
     PH_TRY(launch_check("k_ramanujan"));

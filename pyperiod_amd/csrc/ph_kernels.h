@@ -949,10 +949,26 @@ __global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, i
 //   where E_q = sum_{d | q} mu(q/d) P_d = prod_{prime r | q} (I - P_{q/r}) is the projector onto
 //   the Ramanujan subspace (P_d = mean over the q/d cosets mod d), and
 //   norms[q] = sum_j cnt_q[j] * out_j^2.
-//   wave-per-q: the fold uses the chunked wave fold (S_q lands in a per-wave LDS strip), the
-//   projector is applied in place, one prime factor at a time.  16 waves share one window.
+//
+//   Hierarchical folds.  Only the periods of the upper half of the range, Q in (q_hi/2, q_hi]
+//   ("roots"), are folded from the window (N reads each, chunked wave fold into the wave's LDS
+//   strip A).  Every smaller period q has a multiple Q among the roots and S_q[i] = sum_t
+//   S_Q[i + t q] is a fold of the STRIP (Q reads instead of N): the host hands every q <= q_hi/2
+//   to one root ("children").  Children are folded from A into the scratch strip B and filtered
+//   there; the root itself is filtered in place last.
+//
+//   The projector is applied one prime factor at a time, in place.  A step with d = q/r cosets
+//   uses lane-per-coset when d >= 64 and a row-split mapping (64/d groups of d lanes, shuffle
+//   tree) when d < 64, so that a large prime factor never serialises a coset in one lane.
+//   One wavefront works on one root at a time; the wavefronts of a workgroup share the window.
 // ======================================================================================
-constexpr int kRamBlock = 1024;
+constexpr int kRamMaxWaves = 16;
+
+struct RamRoot {
+  int q;       // root period, folded from the window
+  int c0, c1;  // its children: child_q[c0 .. c1)
+  int emit;    // 1: norms[q] is wanted (q >= q_lo)
+};
 
 template <typename T, int C, int U, bool LW>
 __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0,
@@ -970,159 +986,164 @@ __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p
   }
 }
 
-// Class sums of one pass over the window at base period b with M row classes (row r belongs to
-// class r mod M): a[u][c] = sum over rows r = u (mod M) of x[r b + 64 c + lane], for all C chunks
-// of the base at once (b <= 64 C).  Rows past the last one and the part of the last row past N
-// read the zeroed pad behind the window (b <= 256 here, so both stay inside it).
-template <typename T, int M, int C, bool LW>
-__device__ __forceinline__ void ram_fold_classes(const T* __restrict__ xs, int N, int b, int rows, int lane,
-                                                 double (&a)[M][C]) {
-  const typename Win<T, LW>::ptr ptr = Win<T, LW>::cast(xs) + lane;
-#pragma unroll
-  for (int u = 0; u < M; ++u)
-#pragma unroll
-    for (int c = 0; c < C; ++c) a[u][c] = 0.0;
-  for (int r = 0; r < rows; r += M) {
-    T v[M][C];
-#pragma unroll
-    for (int u = 0; u < M; ++u) {
-      const int off = (r + u < rows) ? (r + u) * b : N;  // wave-uniform; N = first pad element
-#pragma unroll
-      for (int c = 0; c < C; ++c) v[u][c] = ptr[off + 64 * c];
+__device__ __forceinline__ void ram_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Row-split coset sums of s[0 .. len) modulo d < 64 (d | len): lane = g d + i (g < G = 64 / d) adds
+// s[lane + k G d]; the G partial sums of a coset are combined with a shuffle tree.  Returns the coset
+// total in EVERY lane of the coset's column (lane mod d), 0 in the idle lanes >= G d.
+__device__ __forceinline__ double strip_cosets_small(const double* __restrict__ s, int len, int d, int lane) {
+  const int G = 64 / d, L = G * d;
+  double part = 0.0;
+  if (lane < L)
+    for (int idx = lane; idx < len; idx += L) part += s[idx];
+  int sft = 1;
+  while (sft < G) sft <<= 1;
+  for (sft >>= 1; sft >= 1; sft >>= 1) {
+    const int src = lane + sft * d;
+    const double o = __shfl(part, src & (kWave - 1), kWave);
+    part += (src < L) ? o : 0.0;
+  }
+  const int g = (lane * ((65536 + d - 1) / d)) >> 16;  // lane / d for lane < 64
+  const double tot = __shfl(part, lane - g * d, kWave);  // the column's total sits in its first row group
+  return lane < L ? tot : 0.0;
+}
+
+// dst[i] = sum_t src[i + t q], i < q  (q | len): the fold of a folded strip.
+__device__ __forceinline__ void strip_fold(const double* __restrict__ src, int len, int q,
+                                           double* __restrict__ dst, int lane) {
+  if (q < 64) {
+    const double tot = strip_cosets_small(src, len, q, lane);
+    if (lane < q) dst[lane] = tot;
+    return;
+  }
+  const int k = len / q;
+  for (int i = lane; i < q; i += kWave) {
+    double a0 = 0.0, a1 = 0.0;
+    int t = 0;
+    for (; t + 2 <= k; t += 2) {
+      a0 += src[i + t * q];
+      a1 += src[i + (t + 1) * q];
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < M; ++u)
-#pragma unroll
-      for (int c = 0; c < C; ++c) a[u][c] += (double)v[u][c];
+    if (t < k) a0 += src[i + t * q];
+    dst[i] = a0 + a1;
   }
 }
 
+// One factor (I - P_d) of the projector, in place: every element of s[0 .. q) loses the mean of its
+// coset modulo d (r = q / d elements per coset).  Each lane reads and writes only its own elements.
+__device__ __forceinline__ void strip_remove_coset_means(double* __restrict__ s, int q, int d, int lane) {
+  const int r = q / d;
+  const double inv_r = 1.0 / (double)r;
+  if (d < 64) {
+    const int L = (64 / d) * d;
+    const double m = strip_cosets_small(s, q, d, lane) * inv_r;
+    if (lane < L)
+      for (int idx = lane; idx < q; idx += L) s[idx] -= m;
+    return;
+  }
+  for (int i = lane; i < d; i += kWave) {
+    if (r <= 8) {  // the usual case (q <= 512): values stay in registers between the sum and the update
+      double v[8];
+      double m = 0.0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        v[t] = t < r ? s[i + t * d] : 0.0;
+        m += v[t];
+      }
+      m *= inv_r;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < r) s[i + t * d] = v[t] - m;
+    } else {
+      double m = 0.0;
+      for (int t = 0; t < r; ++t) m += s[i + t * d];
+      m *= inv_r;
+      for (int t = 0; t < r; ++t) s[i + t * d] -= m;
+    }
+  }
+}
+
+// s holds S_q: apply E_q in place and reduce to norms[q] (all lanes get it).
+__device__ __forceinline__ double ram_emit(double* __restrict__ s, int q, const PGeom* __restrict__ geom,
+                                           const int* __restrict__ pr_off, const int* __restrict__ pr_d,
+                                           const int* __restrict__ totient, int lane) {
+  for (int k = pr_off[q]; k < pr_off[q + 1]; ++k) {
+    strip_remove_coset_means(s, q, pr_d[k], lane);
+    ram_wave_sync();
+  }
+  const int rows = geom[q].rows, nfull = geom[q].nfull;
+  const double scale = (double)q / (double)totient[q];
+  const double s2 = scale * scale;
+  double acc = 0.0;
+  for (int j = lane; j < q; j += kWave) {
+    const double o = s[j] * s2;
+    acc += (double)(j < nfull ? rows : rows - 1) * o * o;
+  }
+  return wave_sum(acc);
+}
+
 template <typename T, bool LW>
-__global__ __launch_bounds__(kRamBlock) void k_ramanujan(const T* __restrict__ x, int N, int q_lo, int q_hi,
-                                                         const PGeom* __restrict__ geom,
-                                                         const PassPlan* __restrict__ plan, int n_pass,
-                                                         const int* __restrict__ pr_off,
-                                                         const int* __restrict__ pr_d,
-                                                         const int* __restrict__ totient, T* gwin,
-                                                         double* __restrict__ out) {
+__global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __restrict__ x, int N, int q_hi,
+                                                                const PGeom* __restrict__ geom,
+                                                                const RamRoot* __restrict__ roots, int n_root,
+                                                                const int* __restrict__ child_q,
+                                                                const int* __restrict__ pr_off,
+                                                                const int* __restrict__ pr_d,
+                                                                const int* __restrict__ totient, T* gwin,
+                                                                double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* xs = window_buf<T, LW>(cv, gwin, N + kPad);
   const int nw = blockDim.x >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
-  double* sbuf = cv.take<double>((size_t)nw * q_hi) + (size_t)wv * q_hi;  // this wave's S_q
+  const int lenA = q_hi, lenB = q_hi / 2 > 0 ? q_hi / 2 : 1;
+  double* sA = cv.take<double>((size_t)nw * lenA) + (size_t)wv * lenA;  // this wave's root fold S_Q
+  double* sB = cv.take<double>((size_t)nw * lenB) + (size_t)wv * lenB;  // scratch for one child
 
   const int64_t w = blockIdx.x;
   load_window(x + w * (int64_t)N, xs, N);
   zero_pad(xs, N);
   double* orow = out + w * (int64_t)(q_hi + 1);
   __syncthreads();
-  auto wave_sync = [] {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  // sbuf holds S_q: apply E_q in place, reduce to norms[q]
-  auto emit = [&](int q) {
-    wave_sync();
-    const int rows = geom[q].rows, nfull = geom[q].nfull;
-    // ---- E_q in place: for every prime r | q subtract the mean over the r cosets mod q/r
-    for (int k = pr_off[q]; k < pr_off[q + 1]; ++k) {
-      const int d = pr_d[k];  // q / r
-      const int r = q / d;
-      const double inv_r = 1.0 / (double)r;
-      for (int i = lane; i < d; i += kWave) {
-        double m = 0.0;
-        for (int t = 0; t < r; ++t) m += sbuf[i + t * d];
-        m *= inv_r;
-        for (int t = 0; t < r; ++t) sbuf[i + t * d] -= m;
-      }
-      wave_sync();
-    }
-    // ---- norms[q] = sum_j cnt_j ((q/phi)^2 (E_q S)_j)^2
-    const double scale = (double)q / (double)totient[q];
-    const double s2 = scale * scale;
-    double acc = 0.0;
-    for (int j = lane; j < q; j += kWave) {
-      const double o = sbuf[j] * s2;
-      acc += (double)(j < nfull ? rows : rows - 1) * o * o;
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) orow[q] = acc;
-    wave_sync();
-  };
 
-  // The pass plan of the norm sweeps (period_hip.hip): a pass at base b with m row classes gives
-  // S_b, S_2b (m >= 2) and S_4b (m == 4) for the loads of one fold.  Multi-class bases are <= q_hi/2
-  // <= 256 here (the class sums of the whole base fit in registers, rows past the window read the
-  // zero pad); larger q_hi falls back to single passes on the host side of the plan.
-  for (int i = wv; i < n_pass; i += nw) {
-    const int b = plan[i].p, m = plan[i].m;
-    const int rows = geom[b].rows, nfull = geom[b].nfull;
-    if (b < 64) {
-      const double tot = wave_fold_small(xs, N, b, lane);  // row-split path, S_b[lane] in the lanes below b
-      if (lane < b) sbuf[lane] = tot;
-      emit(b);
-    } else if (m <= 1) {
-      const int nchunks = (b + 63) >> 6;
-      int c0 = 0;
-      for (; c0 + 4 <= nchunks; c0 += 4) fold_store_group<T, 4, 2, LW>(xs, b, rows, nfull, c0, lane, sbuf);
-      switch (nchunks - c0) {
-        case 3: fold_store_group<T, 3, 2, LW>(xs, b, rows, nfull, c0, lane, sbuf); break;
-        case 2: fold_store_group<T, 2, 4, LW>(xs, b, rows, nfull, c0, lane, sbuf); break;
-        case 1: fold_store_group<T, 1, 8, LW>(xs, b, rows, nfull, c0, lane, sbuf); break;
+  for (int i = wv; i < n_root; i += nw) {
+    const int Q = roots[i].q, c0 = roots[i].c0, c1 = roots[i].c1;
+    // ---- S_Q from the window
+    if (Q < 64) {
+      const double tot = wave_fold_small(xs, N, Q, lane);  // row-split path, S_Q[lane] in the lanes below Q
+      if (lane < Q) sA[lane] = tot;
+    } else {
+      const int rows = geom[Q].rows, nfull = geom[Q].nfull;
+      const int nchunks = (Q + 63) >> 6;
+      int k0 = 0;
+      for (; k0 + 4 <= nchunks; k0 += 4) fold_store_group<T, 4, 2, LW>(xs, Q, rows, nfull, k0, lane, sA);
+      switch (nchunks - k0) {
+        case 3: fold_store_group<T, 3, 2, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
+        case 2: fold_store_group<T, 2, 4, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
+        case 1: fold_store_group<T, 1, 8, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
         default: break;
       }
-      emit(b);
-    } else if (m == 2) {
-      double a[2][4];
-      ram_fold_classes<T, 2, 4, LW>(xs, N, b, rows, lane, a);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int j = 64 * c + lane;
-        if (j < b) {
-          sbuf[j] = a[0][c];
-          sbuf[j + b] = a[1][c];
-        }
-      }
-      emit(2 * b);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int j = 64 * c + lane;
-        if (j < b) sbuf[j] = a[0][c] + a[1][c];
-      }
-      emit(b);
-    } else {
-      double a[4][2];
-      ram_fold_classes<T, 4, 2, LW>(xs, N, b, rows, lane, a);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int j = 64 * c + lane;
-        if (j < b) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) sbuf[j + u * b] = a[u][c];
-        }
-      }
-      emit(4 * b);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int j = 64 * c + lane;
-        if (j < b) {
-          sbuf[j] = a[0][c] + a[2][c];
-          sbuf[j + b] = a[1][c] + a[3][c];
-        }
-      }
-      emit(2 * b);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int j = 64 * c + lane;
-        if (j < b) sbuf[j] = (a[0][c] + a[2][c]) + (a[1][c] + a[3][c]);
-      }
-      emit(b);
     }
+    ram_wave_sync();
+    // ---- children: fold of the strip, filtered in the scratch strip
+    for (int c = c0; c < c1; ++c) {
+      const int q = child_q[c];
+      strip_fold(sA, Q, q, sB, lane);
+      ram_wave_sync();
+      const double v = ram_emit(sB, q, geom, pr_off, pr_d, totient, lane);
+      if (lane == 0) orow[q] = v;
+      ram_wave_sync();  // sB is rewritten by the next child
+    }
+    if (roots[i].emit) {
+      const double v = ram_emit(sA, Q, geom, pr_off, pr_d, totient, lane);
+      if (lane == 0) orow[Q] = v;
+    }
+    ram_wave_sync();  // sA is rewritten by the next root
   }
 }
 

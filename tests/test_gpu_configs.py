@@ -7,7 +7,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import elem_err, rel_err
 from oracle import period_oracle as po
 from pyperiod_amd.synth import multi_sinusoid_batch, multi_sinusoid_window
 
@@ -88,19 +88,28 @@ def test_config4_full_batch_device_resident(eng):
 
 
 def test_config3_ramanujan_batch(eng, golden):
-    """Config 3 shape: N=8192, Pmax=512, a batch of windows in one launch."""
-    W, n, pmax = 256, 8192, 512
+    """BASELINE config 3 as stated: N=8192, Pmax=512, the whole 4096-window batch in one launch
+    (device-resident), every q in [2, 512] checked."""
+    import torch
+
+    W, n, pmax = 4096, 8192, 512
     x = multi_sinusoid_batch(0, W, n)
-    out = eng.ramanujan_norms(x, 2, pmax)
-    assert out.shape == (W, pmax + 1) and not out[:, :2].any() and np.all(out[:, 2:] >= 0)
+    xd = torch.from_numpy(x).cuda()
+    out = eng.ramanujan_norms(xd, 2, pmax).cpu().numpy()
+    assert out.shape == (W, pmax + 1) and not out[:, :2].any() and np.all(out[:, 2:] > 0)
     g = golden("ramanujan")
-    assert rel_err(out[1, :65], g["norms_n8192_pmax64"]) < 1e-5  # the reference's answer for window 1
-    want = po.ramanujan_norms_folded(x[7], 2, 96)
-    assert rel_err(out[7, :97], want) < TOL
-    # the planted sinusoid periods dominate: the strongest q is one of the three integer periods
-    # (or a multiple within Pmax) of the generator for most windows
+    assert rel_err(out[1, :65], g["norms_n8192_pmax64"]) < 1e-5  # the reference's answer for window 1, q <= 64
+    g3 = golden("ramanujan_c3")
+    for w in (0, 1):  # the reference itself for q = 2 .. 512 (float32 accumulation: 1e-5)
+        assert rel_err(out[w], g3[f"norms_n8192_pmax512_w{w}"]) < 1e-5
+        assert elem_err(out[w], g3[f"norms_n8192_pmax512_w{w}"], 1e-4) < 1e-4
+    for w in (7, 4095):  # the fp64 folded oracle, all 511 periods, entry by entry
+        want = po.ramanujan_norms_folded(x[w], 2, pmax)
+        assert rel_err(out[w], want) < TOL and elem_err(out[w], want) < 1e-9
     single = eng.ramanujan_norms(x[3:4], 2, pmax)
     assert np.array_equal(single[0], out[3])  # batch == per-window
+    sub = eng.ramanujan_norms(x[3:4], 100, 300)  # a sub-range takes other roots: same values to rounding
+    assert not sub[0, :100].any() and rel_err(sub[0, 100:], out[3, 100:301]) < 1e-12
     # exactness of the subspace split: sum over q | n of E_q energy == energy of the n-periodic part
     y = po.project(x[5][:8190], 90)  # a 90-periodic signal (8190 = 91 * 90)
     r = eng.ramanujan_norms(y[None, :], 1, 90)[0]
@@ -108,6 +117,56 @@ def test_config3_ramanujan_batch(eng, golden):
     # orthogonality is exact only for q | N (otherwise the finite window leaks)
     others = [q for q in range(1, 91) if 90 % q and 8190 % q == 0]
     assert len(others) >= 10 and r[others].max() < 1e-18 * r[divs].max()
+
+
+def test_ramanujan_default_range(eng, golden):
+    """RamanujanPeriods().find_periods(x) with the reference's default max_length = len(x) // 3
+    (RamanujanPeriods.py:68-69) at N = 4096 .. 16384: the per-wavefront strips are sized by the range."""
+    from pyperiod_amd import RamanujanPeriods
+
+    rp = RamanujanPeriods()
+    x = multi_sinusoid_window(3, 4096)
+    got = rp.find_periods(x)
+    want = golden("ramanujan_default")["norms_n4096_default_w3"]  # the reference, q = 2 .. 1365
+    assert got.shape == want.shape == (4096 // 3 + 1,)
+    assert rel_err(got, want) < 1e-5 and elem_err(got, want, 1e-4) < 1e-4
+    fold = po.ramanujan_norms_folded(x)
+    assert rel_err(got, fold) < TOL and elem_err(got, fold) < 1e-9
+    for n in (8192, 16384):
+        x = multi_sinusoid_window(4, n)
+        got = rp.find_periods(x)
+        assert got.shape == (n // 3 + 1,) and np.all(got[2:] > 0)
+        qs = [2, 3, 63, 64, 65, 97, 360, 509, 1024, 1365, 2048, n // 6, n // 6 + 1, 2520, n // 3 - 1, n // 3]
+        want = np.array([po.ramanujan_norm_folded_q(x, q) for q in qs])
+        assert elem_err(got[qs], want) < 1e-9, n
+    # fp32 windows and a batch take the same path
+    xb = multi_sinusoid_batch(0, 3, 4096, dtype=np.float32)
+    gb = eng.ramanujan_norms(xb)
+    assert gb.shape == (3, 1366)
+    assert rel_err(gb[1], po.ramanujan_norms_folded(xb[1].astype(np.float64))) < 1e-5
+
+
+def test_ramanujan_find_periods_with_weights(eng, golden):
+    """RamanujanPeriods.find_periods_with_weights (RamanujanPeriods.py:88-122) against the reference run
+    with its two v1 defects repaired in the harness (tests/golden/make_golden.py, shim 4)."""
+    from pyperiod_amd import RamanujanPeriods
+
+    g = golden("ramanujan_weights")
+    for tag, sig, kw in (
+        ("n240", multi_sinusoid_window(0, 240), dict(min_length=2, max_length=80, thresh=0.2)),
+        ("n1000", multi_sinusoid_window(2, 1000), dict(thresh=0.3)),
+        ("n600", multi_sinusoid_window(5, 600), dict(min_length=3, max_length=150, thresh=0.1)),
+    ):
+        out, res = RamanujanPeriods().find_periods_with_weights(sig, **kw)
+        assert np.array_equal(out["periods"], g[f"{tag}_periods"]), tag
+        assert rel_err(out["norms"], g[f"{tag}_norms"]) < 1e-5
+        assert [int(k) for k in out["basis_dictionary"]] == list(g[f"{tag}_dict_keys"])
+        assert list(out["basis_dictionary"].values()) == list(g[f"{tag}_dict_vals"])
+        assert out["subspaces"].shape == (int(g[f"{tag}_dict_vals"].sum()), sig.size)
+        assert rel_err(out["weights"], g[f"{tag}_weights"]) < 1e-8 and rel_err(res, g[f"{tag}_residual"]) < 1e-8
+    # a caller-supplied test function overrides thresh (RamanujanPeriods.py:93-94)
+    out, res = RamanujanPeriods().find_periods_with_weights(multi_sinusoid_window(0, 240), 2, 80, test_function=lambda v: np.array([7, 12]))
+    assert list(out["periods"]) == [7, 12] and list(out["basis_dictionary"].values()) == [7, 11]
 
 
 def test_config5_fp32_blocks(eng):
@@ -145,6 +204,47 @@ def test_config5_fp32_blocks(eng):
 
     sw = eng.sweep(x32[:1], 2, 600, _ffi.PH_SWEEP_NORM_GAMMA)[0]
     assert rel_err(sw, po.sweep_norms(x64[0], 2, 600, gamma=True)) < 1e-4
+
+
+def test_config5_device_loop_fp32_n16384(eng, golden):
+    """Config 5's shape and dtype through ph_qo_find_periods: fp32 windows of N = 16384, the whole
+    greedy loop on the device.  Against the reference's own answer on the rounded input (fixture) and
+    the fp64 oracle: periods / rows kept exact, norms / weights / residual 1e-4 (build-defined fp32 bar)."""
+    g = golden("qoperiods_c5")
+    n = 16384
+    for tag, w, kw in (
+        ("w0", 0, dict(num=3, thresh=0.1, min_length=8, max_length=300)),
+        ("w7", 7, dict(num=4, thresh=0.05, min_length=8, max_length=300)),
+    ):
+        x32 = multi_sinusoid_window(w, n, dtype=np.float32)[None, :]
+        per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(x32, kw["num"], kw["thresh"], kw["min_length"], kw["max_length"], 1024)
+        assert st[0] == 0 and resid.dtype == np.float32
+        nrep, nb = counts[0]
+        assert np.array_equal(per[0, :nrep], g[f"fp_{tag}_periods"]), tag
+        assert list(keeps[0, :nb]) == list(g[f"fp_{tag}_dict_vals"]) and list(per[0, :nb]) == list(g[f"fp_{tag}_dict_keys"])
+        assert rel_err(nrm[0, :nrep], g[f"fp_{tag}_norms"]) < 1e-4
+        k = int(keeps[0, :nb].sum())
+        assert rel_err(wts[0, :k], g[f"fp_{tag}_weights"]) < 1e-4
+        assert rel_err(resid[0], g[f"fp_{tag}_residual"]) < 1e-4
+    # a batch of fp32 windows against the fp64 oracle on the rounded inputs
+    xb = multi_sinusoid_batch(20, 4, n, dtype=np.float32)
+    per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(xb, 3, 0.1, 8, 300, 1024)
+    for w in range(4):
+        out, res = po.qo_find_periods(xb[w].astype(np.float64), 3, 0.1, 8, 300)
+        nrep, nb = counts[w]
+        assert st[w] == 0 and np.array_equal(per[w, :nrep], out["periods"]), w
+        assert list(keeps[w, :nb]) == list(out["basis_dictionary"].values())
+        k = int(keeps[w, :nb].sum())
+        assert rel_err(nrm[w, :nrep], out["norms"]) < 1e-4
+        assert rel_err(wts[w, :k], out["weights"]) < 1e-4 and rel_err(resid[w], res) < 1e-4
+    # the same windows in fp64 meet the fp64 bar
+    per64, nrm64, keeps64, counts64, wts64, resid64, st64 = eng.qo_find_periods(xb.astype(np.float64), 3, 0.1, 8, 300, 1024)
+    for w in range(4):
+        out, res = po.qo_find_periods(xb[w].astype(np.float64), 3, 0.1, 8, 300)
+        nrep, nb = counts64[w]
+        k = int(keeps64[w, :nb].sum())
+        assert np.array_equal(per64[w, :nrep], out["periods"]) and rel_err(nrm64[w, :nrep], out["norms"]) < TOL
+        assert rel_err(wts64[w, :k], out["weights"]) < 1e-8 and rel_err(resid64[w], res) < 1e-8
 
 
 def test_fp32_algorithms_track_the_fp64_oracle(eng):

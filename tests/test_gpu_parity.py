@@ -12,7 +12,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import elem_err, rel_err
 from oracle import period_oracle as po
 from pyperiod_amd.synth import multi_sinusoid_batch, multi_sinusoid_window, readme_window
 
@@ -117,6 +117,8 @@ def test_sweep_matches_reference_golden(eng, golden):
     for w in range(4):
         assert rel_err(plain[w], g[f"plain_w{w}"]) < TOL
         assert rel_err(gamma[w], g[f"gamma_w{w}"]) < TOL
+        # entry by entry (north_star: 1e-10 *relative*): weak small-p entries meet the same bar
+        assert elem_err(plain[w], g[f"plain_w{w}"]) < TOL and elem_err(gamma[w], g[f"gamma_w{w}"]) < TOL
     maxabs = eng.sweep(x[:1], 2, n // 3, _ffi.PH_SWEEP_MAXABS)[0]
     assert np.array_equal(maxabs, g["maxabs_w0"])  # row-order sums: bit-identical
     for trunc, orth in FLAGS[1:]:
@@ -150,7 +152,7 @@ def test_m_best_matches_reference_golden(eng, golden, name, gamma):
     assert per.dtype == np.uint32 and not st.any()
     for w in range(4):
         assert np.array_equal(per[w], g[f"{name}_w{w}_periods"]), w
-        assert rel_err(pw[w], g[f"{name}_w{w}_powers"]) < TOL
+        assert rel_err(pw[w], g[f"{name}_w{w}_powers"]) < TOL and elem_err(pw[w], g[f"{name}_w{w}_powers"]) < TOL
     assert rel_err(bs[1], g[f"{name}_w1_bases"]) < TOL
     x = multi_sinusoid_batch(4, 2, 1500)
     per, pw, bs, st = eng.m_best(x, 6, 300, 3, gamma)
@@ -166,6 +168,19 @@ def test_m_best_matches_reference_golden(eng, golden, name, gamma):
         per, pw, bs, st = eng.m_best(multi_sinusoid_window(6, 900)[None, :], 5, None, 2, gamma, trunc, orth)
         assert np.array_equal(per[0], g[tag + "_periods"]), tag
         assert rel_err(pw[0], g[tag + "_powers"]) < TOL and rel_err(bs[0], g[tag + "_bases"]) < TOL
+
+
+@pytest.mark.parametrize("name,gamma", [("m_best_gamma", True), ("m_best", False)])
+def test_m_best_step2_splits_match_reference_golden(eng, golden, name, gamma):
+    """Fixtures in which step 2 really splits a row (np.insert fires in the reference,
+    Periods.py:581-594): in gamma mode they pin the stale-`p` divisor of Periods.py:559,572."""
+    g = golden("m_best_split")
+    for n, ml, num, w in g["cases"]:
+        tag = f"{name}_n{n}_ml{ml}_num{num}_w{w}"
+        per, pw, bs, st = eng.m_best(multi_sinusoid_window(int(w), int(n))[None, :], int(num), int(ml), 2, gamma)
+        assert st[0] == 0 and np.array_equal(per[0], g[tag + "_periods"]), tag
+        assert rel_err(pw[0], g[tag + "_powers"]) < TOL and elem_err(pw[0], g[tag + "_powers"]) < 1e-9, tag
+        assert rel_err(bs[0], g[tag + "_bases"]) < TOL, tag
 
 
 def test_m_best_batch_vs_oracle(eng):
@@ -212,6 +227,40 @@ def test_small_to_large_matches_reference_golden(eng, golden):
         assert rel_err(np.array(bs).reshape(len(per), 1200), g[tag + "_bases"]) < TOL
     per, pw, _ = Periods().small_to_large(multi_sinusoid_window(3, 600), thresh=0.02, n_periods=100)
     assert per == list(g["n600_np100_periods"]) and rel_err(pw, g["n600_np100_powers"]) < TOL
+
+
+def test_small_to_large_device_pointer_cap_overflow_is_reported(eng):
+    """PH_FLAG_DEVICE callers: a too small `cap` must not pass silently."""
+    import torch
+
+    from pyperiod_amd import _ffi
+
+    x = multi_sinusoid_batch(60, 3, 500)
+    xd = torch.from_numpy(x).cuda()
+    counts, per, pw, bs, st = eng.small_to_large(xd, 0.001, cap=2)  # the engine sees PH_E_CAP and retries
+    assert per.shape[1] >= int(counts.max()) > 2 and int(st.abs().max()) == 0
+    for w in range(3):
+        rper, rpw, _ = po.small_to_large(x[w], 0.001)
+        assert list(per[w, : int(counts[w])].cpu().numpy()) == rper
+    counts, per, pw, bs, st = eng.small_to_large(xd, 0.001, cap=2, nosync=True)  # opt-out: status says so
+    assert per.shape[1] == 2 and (st.cpu().numpy() == _ffi.PH_ST_CAP).all()
+    with pytest.raises(_ffi.CapacityError):  # the raw ABI returns PH_E_CAP for device pointers too
+        c2 = torch.empty(3, dtype=torch.int32, device="cuda")
+        p2 = torch.empty((3, 2), dtype=torch.int32, device="cuda")
+        w2 = torch.empty((3, 2), dtype=torch.float64, device="cuda")
+        s2 = torch.empty(3, dtype=torch.int32, device="cuda")
+        _ffi.check(eng._lib.ph_small_to_large(eng._ctx, xd.data_ptr(), _ffi.PH_F64, 3, 500, 0.001, -1, None, None, 0,
+                                             _ffi.PH_FLAG_DEVICE, 2, c2.data_ptr(), p2.data_ptr(), w2.data_ptr(), None, s2.data_ptr()))
+
+
+def test_empty_batch_returns_empty_outputs(eng):
+    """W == 0 (a trailing rank's shard, pyperiod_amd/dist.py): no launch, correctly shaped outputs."""
+    x = np.zeros((0, 256))
+    per, pw, bs, st = eng.m_best(x, 3)
+    assert per.shape == (0, 3) and pw.shape == (0, 3) and bs.shape == (0, 3, 256) and st.shape == (0,)
+    counts, sper, spw, sbs, sst = eng.small_to_large(x, 0.05, cap=8)
+    assert counts.shape == (0,) and sper.shape == (0, 8)
+    assert eng.sweep(x, 2, 50).shape == (0, 49) and eng.ramanujan_norms(x, 2, 40).shape == (0, 41)
 
 
 def test_small_to_large_cap_retry_and_empty(eng):
