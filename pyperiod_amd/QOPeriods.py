@@ -73,145 +73,148 @@ class QOPeriods(Periods):
     # ------------------------------------------------------------------ detection
     def find_periods(self, data, num=None, thresh=None, min_length=2, max_length=None, update_weights=True, **kwargs):
         """Greedy period selection with re-solved weights (QOPeriods.py:313-596).
-        Returns ``(dict(periods, norms, subspaces, weights, basis_dictionary), residual)``."""
+        Returns ``(dict(periods, norms, subspaces, weights, basis_dictionary), residual)``.
+
+        ``orthogonalize=True``: the v1 reference dies on this branch (``best_base`` is never
+        assigned, QOPeriods.py:427-448).  Offered here as its commented-out lines intend: the
+        period is chosen by the orthogonal (Muresan-Parks) powers -- ``get_best_period_orthogonal``
+        on the device -- and its norm is that of the orthogonalised projection of the residual
+        (QOPeriods.py:443-448); the solve is the same as in the plain branch."""
         data = _as_window(data)
         N = len(data)
         if max_length is None:
             max_length = int(np.floor(N / 3))
         if num is None:
             num = N
-        periods = np.zeros(num, dtype=np.uint32)
-        norms = np.zeros(num)
-        res = data.copy()
-        output_weights = np.array([])
-        basis_matricies = np.empty((0, N))
-        basis_dictionary = {}
-        if "test_function" in kwargs:
-            test_function = kwargs["test_function"]
-        else:
-            test_function = lambda self, x, y: rms(y) > (rms(data) * thresh)  # noqa: E731  QOPeriods.py:391
-
         if np.sum(np.abs(data)) <= 1e-16:  # QOPeriods.py:394-406
-            output_bases = {
+            self._output = {
                 "periods": np.array([1]),
                 "norms": np.array([0]),
                 "subspaces": np.ones((1, N)),
                 "weights": np.array([0]),
                 "basis_dictionary": {"1": N},
             }
-            self._output = output_bases
-            return (output_bases, np.zeros(N))
-        output_bases = {"periods": [], "norms": [], "subspaces": [], "weights": [], "basis_dictionary": {}}
-
-        if self._orthogonalize:
-            # QOPeriods.py:429-467: in the v1 reference this branch dies with TypeError
-            # (best_base is never assigned).  Row f-3 of SURVEY.md section 8: not built yet.
-            raise NotImplementedError(
-                "QOPeriods.find_periods(orthogonalize=True) is not implemented; the v1 reference "
-                "raises TypeError on this branch"
-            )
-
-        eng = default_engine()
-        plain = (
-            update_weights
-            and "test_function" not in kwargs
-            and thresh is not None
-            and not self._trunc_to_integer_multiple
-            and self._basis_type == "natural"
-            and (self.window is None or self.window is False)
+            return (self._output, np.zeros(N))
+        custom_test = kwargs.get("test_function")
+        windowed = not (self.window is None or self.window is False)
+        on_device = (
+            update_weights and custom_test is None and thresh is not None and not self._orthogonalize
+            and not self._trunc_to_integer_multiple and self._basis_type == "natural" and not windowed
         )
-        if plain:
-            # the whole greedy loop in one kernel launch (ph_qo_find_periods)
-            done = self._find_periods_device(eng, data, N, num, thresh, min_length, max_length)
+        if on_device:
+            done = self._find_periods_device(default_engine(), data, N, num, thresh, min_length, max_length)
             if done is not None:
                 return done
-        reconstruction = None
-        nonzero_periods = periods[:0]
+        return self._find_periods_host(data, N, num, thresh, min_length, max_length, update_weights, custom_test)
+
+    def _strongest_period(self, eng, res, found, min_length, max_length, update_weights):
+        """(period, gamma norm) of the residual `res`; period 0 = stop (QOPeriods.py:425-478)."""
+        if not self._orthogonalize:  # plain gamma sweep, first maximum == strict '>' scan (:470-478)
+            vals = eng.sweep(res[None, :], min_length, max_length, _ffi.PH_SWEEP_NORM_GAMMA, self._trunc_to_integer_multiple, False)[0]
+            order = np.where(np.isnan(vals), -np.inf, vals)
+            k = int(np.argmax(order))
+            return (min_length + k, vals[k]) if order[k] > 0 else (0, 0)
+        pows = eng.orth_powers(res[None, :], int(max_length), True)[0]
+        if update_weights:  # :435-448
+            best = int(np.argmax(pows))
+            best = best if best > 0 else 1
+        else:  # strongest power not found yet (:450-460)
+            best = next((int(q) for q in np.argsort(-pows, kind="stable") if q not in found), 0)
+        if best < 1:
+            return 0, 0
+        base = eng.project_batch(res[None, :], [best], self._trunc_to_integer_multiple, True)[0, 0]
+        return best, eng.periodic_norm(base[None, :], best)[0]
+
+    def _find_periods_host(self, data, N, num, thresh, min_length, max_length, update_weights, custom_test):
+        """Host-driven greedy loop for the variants the single-launch kernel does not cover (custom
+        test function, update_weights=False, trunc, window, Ramanujan basis, orthogonal selection).
+        Heavy pieces stay on the GPU: the sweep (ph_sweep) or orthogonal powers (ph_orth_powers),
+        W = A x and A A^T as folds (ph_fold_sums), A^T w (ph_tile_sum); the small dense solve uses
+        host LAPACK like the reference (QOPeriods.py:794)."""
+        eng = default_engine()
+        keep_going = custom_test if custom_test is not None else (lambda _self, x, y: rms(y) > rms(data) * thresh)
+        found = np.zeros(num, dtype=np.uint32)
+        gnorm = np.zeros(num)
+        state = {"A": np.empty((0, N)), "dims": {}, "w": np.array([]), "recon": None}
+        res = data.copy()
+        result = {"periods": [], "norms": [], "subspaces": [], "weights": [], "basis_dictionary": {}}
+
+        def resolve(active):
+            # update_weights: dictionary of all periods so far, weights re-solved against the data
+            # (:598-643); otherwise only the newest period's rows are fitted to the residual (:645-714)
+            if update_weights:
+                state["A"], state["dims"], state["w"], state["recon"] = self._update_weights(data, N, active)
+            else:
+                state["A"], state["dims"], state["w"], state["recon"] = self._dont_update_weights(
+                    res, N, active, state["w"], state["A"], state["dims"]
+                )
+
+        def report(active, count):
+            return {
+                "periods": active[:count],
+                "norms": gnorm[:count],
+                "subspaces": state["A"],
+                "weights": state["w"],
+                "basis_dictionary": state["dims"],
+            }
+
+        active = found[:0]
         for i in range(num):
-            if i == 0 or test_function(self, data, reconstruction):
-                # strongest gamma-normalised projection of the residual (QOPeriods.py:470-478)
-                sweep = eng.sweep(
-                    res[None, :], min_length, max_length, _ffi.PH_SWEEP_NORM_GAMMA, self._trunc_to_integer_multiple, False
-                )[0]
-                vals = np.where(np.isnan(sweep), -np.inf, sweep)
-                k = int(np.argmax(vals))  # first maximum == strict '>' scan
-                best_p, best_norm = (min_length + k, sweep[k]) if vals[k] > 0 else (0, 0)
-                periods[i] = best_p
-                norms[i] = best_norm
-                if self._verbose:
-                    print(f"New period: {best_p}")
-                nonzero_periods = periods[periods > 0]
-                try:
-                    if update_weights:
-                        basis_matricies, basis_dictionary, output_weights, reconstruction = self._update_weights(
-                            data, N, nonzero_periods
-                        )
-                        res = data - reconstruction
-                    else:
-                        basis_matricies, basis_dictionary, output_weights, reconstruction = self._dont_update_weights(
-                            res, N, nonzero_periods, output_weights, basis_matricies, basis_dictionary
-                        )
-                        res = res - reconstruction
-                    output_bases = {
-                        "periods": nonzero_periods,
-                        "norms": norms[: len(nonzero_periods)],
-                        "subspaces": basis_matricies,
-                        "weights": output_weights,
-                        "basis_dictionary": basis_dictionary,
-                    }
-                    self._output_bases = output_bases
-                except np.linalg.LinAlgError:  # QOPeriods.py:552-559
-                    break
-            else:  # QOPeriods.py:560-594
-                if update_weights:
-                    basis_matricies, basis_dictionary, output_weights, reconstruction = self._update_weights(
-                        data, N, nonzero_periods
-                    )
-                else:
-                    basis_matricies, basis_dictionary, output_weights, reconstruction = self._dont_update_weights(
-                        res, N, nonzero_periods, output_weights, basis_matricies, basis_dictionary
-                    )
-                output_bases = {
-                    "periods": nonzero_periods[:-1],
-                    "norms": norms[: len(nonzero_periods) - 1],
-                    "subspaces": basis_matricies,
-                    "weights": output_weights,
-                    "basis_dictionary": basis_dictionary,
-                }
-                self._output_bases = output_bases
+            if i > 0 and not keep_going(self, data, state["recon"]):
+                # the period added last broke the test: weights / dictionary of everything found are kept,
+                # the period list drops its last entry (:560-594)
+                resolve(active)
+                result = report(active, len(active) - 1)
+                self._output_bases = result
                 break
-        return (output_bases, res)
+            p, g = self._strongest_period(eng, res, found, min_length, max_length, update_weights)
+            if self._orthogonalize and p < 1:
+                break  # :441-442
+            found[i], gnorm[i] = p, g
+            if self._verbose:
+                print(f"New period: {p}")
+            active = found[found > 0]
+            try:
+                resolve(active)
+            except np.linalg.LinAlgError:  # singular dictionary: keep the previous result (:552-559)
+                break
+            res = (data - state["recon"]) if update_weights else (res - state["recon"])
+            result = report(active, len(active))
+            self._output_bases = result
+        return (result, res)
 
     def _find_periods_device(self, eng, data, N, num, thresh, min_length, max_length):
-        """Assemble the reference's return value from the device loop's compact outputs."""
+        """The whole greedy loop in one kernel launch (ph_qo_find_periods); None when the window /
+        dictionary does not fit the kernel's LDS layout or workspace -- the host-driven loop then runs."""
         # a block adds at most max_length rows: start with room for all of them when that fits
         bound = int(num) * int(max_length if max_length is not None else N // 3)
         kcap = min(2048, max(64, -(-bound // 64) * 64)) if bound <= 2048 else 512
+        while kcap > 64 and not eng.qo_feasible(N, np.float64, kcap, max_length):
+            kcap //= 2
+        if not eng.qo_feasible(N, np.float64, kcap, max_length):
+            return None
         while True:
-            per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(
-                data[None, :], num, thresh, min_length, max_length, kcap
-            )
-            if st[0] == _ffi.PH_ST_CAP and kcap < 2048:
+            per, nrm, keeps, counts, wts, resid, st = eng.qo_find_periods(data[None, :], num, thresh, min_length, max_length, kcap)
+            if st[0] == _ffi.PH_ST_CAP and kcap < 2048 and eng.qo_feasible(N, np.float64, 2 * kcap, max_length):
                 kcap *= 2
                 continue
             break
         if st[0] != _ffi.PH_ST_OK:
-            return None  # dictionary larger than the device workspace: host-driven loop below
+            return None  # dictionary larger than the device workspace: host-driven loop
         n_report, n_blocks = int(counts[0, 0]), int(counts[0, 1])
         if n_blocks == 0:
             return None
         blocks = [(int(per[0, b]), int(keeps[0, b])) for b in range(n_blocks)]
-        basis_dictionary = {str(q): k for q, k in blocks}
-        basis_matricies = np.vstack([self.Pp(q, N, k, self._basis_type) for q, k in blocks])
-        output_bases = {
+        rows = np.vstack([self.Pp(q, N, k, self._basis_type) for q, k in blocks])
+        result = {
             "periods": per[0, :n_report].copy(),
             "norms": nrm[0, :n_report].copy(),
-            "subspaces": basis_matricies,
-            "weights": wts[0, : basis_matricies.shape[0]].copy(),
-            "basis_dictionary": basis_dictionary,
+            "subspaces": rows,
+            "weights": wts[0, : rows.shape[0]].copy(),
+            "basis_dictionary": {str(q): k for q, k in blocks},
         }
-        self._output_bases = output_bases
-        return (output_bases, resid[0].copy())
+        self._output_bases = result
+        return (result, resid[0].copy())
 
     def _solve_structured(self, x, basis_matrix, dictionary):
         """solve_quadratic for a natural-basis dictionary without touching the dense matrix

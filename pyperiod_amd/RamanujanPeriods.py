@@ -41,26 +41,28 @@ class RamanujanPeriods(QOPeriods):
         return norms
 
     def find_periods_with_weights(self, x, min_length=2, max_length=None, thresh=0.2, **kwargs):
-        """RamanujanPeriods.py:88-122 with the two v1 defects repaired (missing `_k`, and the
-        swapped ``(weights, reconstruction)`` unpacking at :109-112)."""
-        x = _as_window(x)
-        norms = self.find_periods(x, min_length, max_length, select_periods=None)
-        if "test_function" in kwargs:
-            test_function = kwargs["test_function"]
+        """Threshold the Ramanujan norms, then fit the natural-basis dictionary of the selected
+        periods to the window (RamanujanPeriods.py:88-122).  The v1 reference cannot run this
+        method (``_k`` is missing and solve_quadratic's pair is unpacked the wrong way round,
+        :109); it is implemented as written otherwise: periods = indices whose norm exceeds
+        ``thresh`` x the largest norm, or whatever ``test_function(norms)`` returns."""
+        sig = _as_window(x)
+        norms = self.find_periods(sig, min_length, max_length)
+        select = kwargs.get("test_function")
+        if select is None:
+            periods = np.flatnonzero(norms / np.abs(np.max(norms)) > thresh)
         else:
-            test_function = lambda v: np.argwhere(v / np.abs(np.max(v)) > thresh).flatten()  # noqa: E731
-        periods = test_function(norms)
-        basis_matricies, basis_dictionary = self.get_subspaces(periods, len(x))
-        output_weights, reconstruction = self._solve_structured(x, basis_matricies, basis_dictionary)
-        output_bases = {
+            periods = select(norms)
+        rows, dims = self.get_subspaces(periods, sig.size)
+        weights, recon = self._solve_structured(sig, rows, dims)  # folds + host LAPACK + tile-sum
+        self._output = {
             "periods": periods,
             "norms": norms[periods],
-            "subspaces": basis_matricies,
-            "weights": output_weights,
-            "basis_dictionary": basis_dictionary,
+            "subspaces": rows,
+            "weights": weights,
+            "basis_dictionary": dims,
         }
-        self._output = output_bases
-        return (output_bases, x - reconstruction)
+        return (self._output, sig - recon)
 
     @staticmethod
     def project(x, basis):
@@ -74,15 +76,12 @@ class RamanujanPeriods(QOPeriods):
         return QOPeriods.Cq(q, s, repetitions, "complex" if type == "complex" else "real")
 
     def Cq_complete(self, q, N=None, normalize=True):
-        """q circular shifts of c_q tiled to N, each L2-normalised (RamanujanPeriods.py:156-169)."""
-        if N is None:
-            N = q
-        N = int(N)
-        cq = self.Cq(q)
-        reps = int(np.ceil(N / q))
-        matrix = np.zeros((q, N))
-        for i in range(q):
-            matrix[i] = np.tile(np.roll(cq, i), reps)[:N]
-            if normalize:
-                matrix[i] /= np.linalg.norm(matrix[i])
-        return matrix
+        """The q circular shifts of c_q, each tiled to N samples and (optionally) scaled to unit
+        L2 norm (RamanujanPeriods.py:156-169): row i, column n = c_q((n - i) mod q), one gather."""
+        q = int(q)
+        N = q if N is None else int(N)
+        table = ramanujan_sum(q).astype(np.float64)
+        rows = table[(np.arange(N)[None, :] - np.arange(q)[:, None]) % q]
+        if normalize:
+            rows /= np.sqrt(np.einsum("ij,ij->i", rows, rows))[:, None]
+        return rows

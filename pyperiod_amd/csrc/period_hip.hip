@@ -904,8 +904,11 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   size_t lds = 2 * carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8);  // update kernel
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, true, (size_t)N * sz, W, &gbuf));
+  // windows longer than the LDS: both kernels work on the residual where it lives (HBM workspace)
+  const bool lds_window = lds <= (size_t)c->lds_limit;
+  if (!lds_window) lds -= carve_bytes(N, sz);
   PH_TRY(check_lds(c, lds, N, "ph_best_frequency"));
-  const size_t lds_spec = carve_bytes(N, sz) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+  const size_t lds_spec = (lds_window ? carve_bytes(N, sz) : 0) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
   PH_TRY(check_lds(c, lds_spec, N, "ph_best_frequency"));
   const int nchunk = (L / 2 + 1 + ph::kBfBlock - 1) / ph::kBfBlock;
   ph::Tables tb{};
@@ -944,20 +947,21 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   PH_HIP(hipMemsetAsync(dstat, 0, (size_t)W * sizeof(int32_t), c->stream));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid_s((unsigned)nchunk, (unsigned)W), grid_u((unsigned)W);
-  PH_TRY(dispatch(dtype, true, [&](auto t, auto) {
+  PH_TRY(dispatch(dtype, lds_window, [&](auto t, auto lw) {
     using T = decltype(t);
-    PH_TRY(allow_lds(ph::k_bf_spectrum<T>, lds_spec));
-    PH_TRY(allow_lds(ph::k_bf_update<T>, lds));
+    constexpr bool LW = decltype(lw)::value;
+    PH_TRY(allow_lds(ph::k_bf_spectrum<T, LW>, lds_spec));
+    PH_TRY(allow_lds(ph::k_bf_update<T, LW>, lds));
     for (int it = 0; it < num; ++it) {
       {
         ProfScope ps_(c, "k_bf_spectrum");
-        hipLaunchKernelGGL(ph::k_bf_spectrum<T>, grid_s, dim3(ph::kBfBlock), lds_spec, c->stream, (const T*)dres, N, L,
+        hipLaunchKernelGGL((ph::k_bf_spectrum<T, LW>), grid_s, dim3(ph::kBfBlock), lds_spec, c->stream, (const T*)dres, N, L,
                            (const double2*)c->twid.p, (const int*)dstat, dpart, dpartk);
       }
       PH_TRY(launch_check("k_bf_spectrum"));
       {
         ProfScope ps_(c, "k_bf_update");
-        hipLaunchKernelGGL(ph::k_bf_update<T>, grid_u, dim3(kBlockWide), lds, c->stream, (T*)dres, N, L, num, it,
+        hipLaunchKernelGGL((ph::k_bf_update<T, LW>), grid_u, dim3(kBlockWide), lds, c->stream, (T*)dres, N, L, num, it,
                            kflags, tb, (T*)gbuf, nchunk, (const double*)dpart, (const int*)dpartk, dnrm,
                            (uint32_t*)dper, (double*)dpow, (T*)dbases, (int*)dstat);
       }
@@ -1110,8 +1114,8 @@ int ph_fold_sums(ph_ctx* c, const void* x, int dtype, int64_t W, int N, const in
   if (!out) return fail(PH_E_ARG, "out is NULL");
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  const size_t lds = carve_bytes(N, sz);
-  PH_TRY(check_lds(c, lds, N, "ph_fold_sums"));
+  const bool lds_window = carve_bytes(N, sz) <= (size_t)c->lds_limit;  // longer windows are folded from HBM / L2
+  const size_t lds = lds_window ? carve_bytes(N, sz) : 0;
   const int *d_p, *d_keep, *d_off;
   int stride;
   PH_TRY(qo_tables(c, p_list, keep, n_p, &d_p, &d_keep, &d_off, &stride));
@@ -1121,21 +1125,15 @@ int ph_fold_sums(ph_ctx* c, const void* x, int dtype, int64_t W, int N, const in
   PH_TRY(st.in(x, (size_t)W * N * sz, &dx));
   PH_TRY(st.out(B_OUT0, out, (size_t)W * stride * sizeof(double), &dout));
   const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_fold_sums<double>, lds));
-    {
-      ProfScope ps_(c, "k_fold_sums");
-      hipLaunchKernelGGL(ph::k_fold_sums<double>, grid, dim3(kBlock), lds, c->stream, (const double*)dx, N, d_p,
-                         d_keep, d_off, n_p, stride, (double*)dout);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_fold_sums<float>, lds));
-    {
-      ProfScope ps_(c, "k_fold_sums");
-      hipLaunchKernelGGL(ph::k_fold_sums<float>, grid, dim3(kBlock), lds, c->stream, (const float*)dx, N, d_p,
-                         d_keep, d_off, n_p, stride, (double*)dout);
-    }
-  }
+  PH_TRY(dispatch(dtype, lds_window, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_fold_sums<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_fold_sums");
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, c->stream, (const T*)dx, N, d_p, d_keep, d_off, n_p, stride,
+                       (double*)dout);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_fold_sums"));
   return st.finish();
 }
@@ -1336,8 +1334,16 @@ int ph_orth_powers(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int ma
   if (max_p < 2) return fail(PH_E_ARG, "max_p=%d must be >= 2", max_p);
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
-  const size_t lds = carve_bytes(N, sz) + carve_bytes(N, 8) + carve_bytes(max_p, 8);
-  PH_TRY(check_lds(c, lds, N, "ph_orth_powers"));
+  // window + autocorrelation + clipped eq. 3 values in LDS when they fit, otherwise the window is read
+  // from HBM / L2 and the two work arrays live in an HBM workspace
+  size_t lds = carve_bytes(N, sz) + carve_bytes(N, 8) + carve_bytes(max_p, 8);
+  const bool lds_window = lds <= (size_t)c->lds_limit;
+  double* gws = nullptr;
+  if (!lds_window) {
+    lds = 0;
+    PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * ((size_t)N + max_p) * sizeof(double)));
+    gws = static_cast<double*>(c->buf[B_WS1].p);
+  }
   // divisors d of q with mu(q/d) != 0, for q < max_p
   std::vector<int32_t> mu(max_p, 1), off(max_p + 1, 0), dd, dm;
   {
@@ -1372,21 +1378,15 @@ int ph_orth_powers(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int ma
   PH_TRY(st.out(B_OUT1, eq3, (size_t)W * max_p * sizeof(double), &de));
   PH_TRY(st.out(B_OUT2, powers, (size_t)W * max_p * sizeof(double), &dp));
   const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_orth_powers<double>, lds));
-    {
-      ProfScope ps_(c, "k_orth_powers");
-      hipLaunchKernelGGL(ph::k_orth_powers<double>, grid, dim3(kBlockWide), lds, c->stream, (const double*)dx, N, max_p,
-                         normalize, d_off, d_d, d_mu, (double*)dr, (double*)de, (double*)dp);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_orth_powers<float>, lds));
-    {
-      ProfScope ps_(c, "k_orth_powers");
-      hipLaunchKernelGGL(ph::k_orth_powers<float>, grid, dim3(kBlockWide), lds, c->stream, (const float*)dx, N, max_p,
-                         normalize, d_off, d_d, d_mu, (double*)dr, (double*)de, (double*)dp);
-    }
-  }
+  PH_TRY(dispatch(dtype, lds_window, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_orth_powers<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_orth_powers");
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlockWide), lds, c->stream, (const T*)dx, N, max_p, normalize, d_off, d_d, d_mu,
+                       gws, (double*)dr, (double*)de, (double*)dp);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_orth_powers"));
   return st.finish();
 }

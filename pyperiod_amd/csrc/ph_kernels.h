@@ -550,10 +550,25 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         const int q = p + lane;
         bool flag = false;
         if (q <= hi) {
+          // The decision below is taken on t_e = fl(sum (r - m)^2), the screen has t_s = rsq - psq.
+          // Both approximate T = ||r||^2 - ||P r||^2:
+          //   |psq - ||P r||^2| <= (2 R + q/64 + 16) eps ||r||^2   (S_j: R-term sums, |S_j| A_j / cnt_j <= Q_j
+          //                                                         by Cauchy-Schwarz; then a positive sum)
+          //   |rsq - ||r||^2|, |t_e - T| <= (N / 512 + 16) eps ||r||^2 each (strided partial sums + tree)
+          // so |t_s - t_e| <= D = (1.5 N + 256) eps rsq for every q >= 2 (2 R <= N, q / 64 <= N / 128).
+          // float windows: the means and r - m are rounded to float, adding (4 + R^2 eps_f) eps_f rsq.
+          // |sqrt(t_s) - sqrt(t_e)| <= min(D / sqrt(t_s), sqrt(D)); the remaining operations of
+          // (rn - sqrt(t) / sqrtN) / dn are shared by both paths up to 8 eps (<= 1e-13).
           const double tsq = fmax(rsq - psq[lane], 0.0);
           const double est = (rn - sqrt(tsq) / sqrtN) / dn;
-          const double err =
-              (4096.0 * 2.220446049250313e-16 * rsq / fmax(sqrt(tsq), 1e-300)) / sqrtN / dn + 1e-13;
+          double kappa = (1.5 * (double)N + 256.0) * 2.220446049250313e-16;
+          if (sizeof(T) == 4) {
+            const double rf = (double)geom[q].rows * 5.9604644775390625e-08;
+            kappa += (4.0 + rf * (double)geom[q].rows) * 5.9604644775390625e-08;
+          }
+          const double D = kappa * rsq;
+          const double dsq = fmin(D / fmax(sqrt(tsq), 1e-300), sqrt(D));
+          const double err = dsq / sqrtN / dn + 1e-13;
           flag = !(est + err <= thresh);  // NaN -> evaluate
         }
         const unsigned long long mask = __ballot(flag);
@@ -817,24 +832,28 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // ======================================================================================
 constexpr int kBfBlock = 256;
 
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBfBlock) void k_bf_spectrum(const T* __restrict__ res, int N, int L,
                                                           const double2* __restrict__ tw,
                                                           const int* __restrict__ status,
                                                           double* __restrict__ part_m2, int* __restrict__ part_k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = cv.take<T>(N);
+  const int64_t w = blockIdx.y;
+  const T* xs = res + w * (int64_t)N;  // LW == false: every thread walks the residual in HBM / L2 (broadcast reads)
+  T* stage = LW ? cv.take<T>(N) : nullptr;
   double* wbest = cv.take<double>(kMaxWaves);
   int* wbestp = cv.take<int>(kMaxWaves);
-  const int64_t w = blockIdx.y;
   const int chunk = blockIdx.x, nchunk = gridDim.x;
   if (status[w] != 0) return;  // the reference has raised for this window already
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int M = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
-  load_window(res + w * (int64_t)N, xs, N);
-  __syncthreads();
+  if constexpr (LW) {
+    load_window(xs, stage, N);
+    __syncthreads();
+    xs = stage;
+  }
   double best = -1.0;
   int bestk = 0;  // bin + 1; 0 = none
   const int k = chunk * (int)blockDim.x + tid;
@@ -874,7 +893,7 @@ __global__ __launch_bounds__(kBfBlock) void k_bf_spectrum(const T* __restrict__ 
   }
 }
 
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, int N, int L, int num, int it,
                                                           unsigned flags, Tables tb, T* __restrict__ gbuf, int nchunk,
                                                           const double* __restrict__ part_m2,
@@ -884,10 +903,11 @@ __global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, i
                                                           int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N);
+  const int64_t w = blockIdx.x;
+  // LW == false: the residual is projected where it lives (the HBM workspace `res`)
+  T* work = LW ? cv.take<T>(N) : res + w * (int64_t)N;
   T* buf = gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
-  const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
   T* brow = bases_out + (w * num + it) * (int64_t)N;
   bool dead = status[w] != 0;
@@ -919,8 +939,10 @@ __global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, i
     }
     return;
   }
-  load_window(res + w * (int64_t)N, work, N);
-  __syncthreads();
+  if constexpr (LW) {
+    load_window(res + w * (int64_t)N, work, N);
+    __syncthreads();
+  }
   double dn;
   if (it == 0) {
     dn = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
@@ -1150,18 +1172,22 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
 // ======================================================================================
 // QOPeriods building blocks (QOPeriods.py:779-795): W = A x and A^T w for natural-basis A.
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlock) void k_fold_sums(const T* __restrict__ x, int N,
                                                       const int* __restrict__ p_list,
                                                       const int* __restrict__ keep,
                                                       const int* __restrict__ row_off, int n_p, int stride,
                                                       double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Carve cv(smem);
-  T* xs = cv.take<T>(N);
   const int64_t w = blockIdx.x;
-  load_window(x + w * (int64_t)N, xs, N);
-  __syncthreads();
+  const T* xs = x + w * (int64_t)N;  // LW == false: a window longer than the LDS is folded straight from HBM / L2
+  if constexpr (LW) {
+    Carve cv(smem);
+    T* stage = cv.take<T>(N);
+    load_window(xs, stage, N);
+    __syncthreads();
+    xs = stage;
+  }
   double* orow = out + w * (int64_t)stride;
   for (int k = 0; k < n_p; ++k) {
     const int p = p_list[k];
@@ -1542,22 +1568,33 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
 //           = sum_{d | q} mu(q/d) max(e3[d], 0)   (Moebius inversion of the same recursion),
 //   negatives clipped to 0 afterwards, optionally divided by q (:1218-1223).
 // ======================================================================================
-template <typename T>
+template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) void k_orth_powers(const T* __restrict__ x, int N, int max_p, int normalize,
                                                             const int* __restrict__ mob_off,
                                                             const int* __restrict__ mob_d,
                                                             const int* __restrict__ mob_mu,
+                                                            double* __restrict__ gws,
                                                             double* __restrict__ r_out, double* __restrict__ e3_out,
                                                             double* __restrict__ pows_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Carve cv(smem);
-  T* xs = cv.take<T>(N);
-  double* r = cv.take<double>(N);
-  double* m = cv.take<double>(max_p);
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
-  load_window(x + w * (int64_t)N, xs, N);
-  __syncthreads();
+  // LW: window, autocorrelation and clipped eq. 3 values live in LDS.  Otherwise (long windows) the
+  // window is read straight from HBM / L2 and the two work arrays sit in the HBM workspace `gws`.
+  const T* xs = x + w * (int64_t)N;
+  double *r, *m;
+  if constexpr (LW) {
+    Carve cv(smem);
+    T* stage = cv.take<T>(N);
+    r = cv.take<double>(N);
+    m = cv.take<double>(max_p);
+    load_window(xs, stage, N);
+    __syncthreads();
+    xs = stage;
+  } else {
+    r = gws + w * ((int64_t)N + max_p);
+    m = r + N;
+  }
   // autocorrelation: lags k and N-1-k are paired on one thread (N-k plus k+1 products = N+1)
   for (int k = tid; k < (N + 1) / 2; k += blockDim.x) {
     const int k2 = N - 1 - k;
@@ -1568,6 +1605,7 @@ __global__ __launch_bounds__(kBlockWide) void k_orth_powers(const T* __restrict_
     r[k] = a;
     if (k2 != k) r[k2] = b;
   }
+  __threadfence_block();
   __syncthreads();
   if (r_out)
     for (int k = tid; k < N; k += blockDim.x) r_out[w * (int64_t)N + k] = r[k];
@@ -1582,6 +1620,7 @@ __global__ __launch_bounds__(kBlockWide) void k_orth_powers(const T* __restrict_
     if (e3_out) e3_out[w * (int64_t)max_p + q] = v;
     m[q] = fmax(v, 0.0);
   }
+  __threadfence_block();
   __syncthreads();
   for (int q = tid; q < max_p; q += blockDim.x) {
     double v = 0.0;

@@ -87,6 +87,23 @@ def test_config4_full_batch_device_resident(eng):
     assert np.array_equal(pp[7 + 256 * 63], po.m_best(base[7], 10)[0])
 
 
+def test_small_to_large_threshold_on_a_knife_edge(eng):
+    """The screen of k_small_to_large skips a period only when its estimate plus a rigorous bound on
+    its error stays below the threshold.  Plant the threshold within 1e-12 of the
+    drop of an accepted period, on both sides, at N = 16384 (the bound grows with N) and N = 4096:
+    the period list must flip exactly where the oracle's does."""
+    for n, w in ((16384, 3), (4096, 9)):
+        x = multi_sinusoid_window(w, n)
+        rper, rpw, _ = po.small_to_large(x, 0.02)
+        assert len(rper) >= 3
+        for k in (0, len(rper) // 2, len(rper) - 1):
+            for thresh in (rpw[k] - 1e-12, rpw[k] + 1e-12):
+                want_per, want_pw, _ = po.small_to_large(x, thresh)
+                counts, per, pw, _, st = eng.small_to_large(x[None, :], thresh, cap=64, want_bases=False)
+                assert list(per[0, : counts[0]]) == want_per, (n, k, thresh)
+                assert rel_err(pw[0, : counts[0]], want_pw) < TOL
+
+
 def test_config3_ramanujan_batch(eng, golden):
     """BASELINE config 3 as stated: N=8192, Pmax=512, the whole 4096-window batch in one launch
     (device-resident), every q in [2, 512] checked."""
@@ -247,6 +264,48 @@ def test_config5_device_loop_fp32_n16384(eng, golden):
         assert rel_err(wts64[w, :k], out["weights"]) < 1e-8 and rel_err(resid64[w], res) < 1e-8
 
 
+def test_qoperiods_falls_back_to_the_host_loop(eng):
+    """Windows / dictionaries the single-launch kernel cannot hold: QOPeriods.find_periods
+    must not raise -- the host-driven loop (ph_sweep / ph_fold_sums / ph_tile_sum + LAPACK) takes over."""
+    from pyperiod_amd import QOPeriods
+
+    # a dictionary of more rows than fits beside an N = 16384 fp64 window (three periods near 300)
+    t = np.arange(16384, dtype=np.float64)
+    sig = np.sin(2 * np.pi * t / 299.0) + 0.8 * np.sin(2 * np.pi * t / 293.0 + 1.0) + 0.6 * np.sin(2 * np.pi * t / 283.0 + 2.0)
+    sig = sig + 0.01 * np.random.default_rng(5).standard_normal(t.size)
+    out, res = QOPeriods().find_periods(sig, num=3, thresh=0.01, min_length=200, max_length=300)
+    want, wres = po.qo_find_periods(sig, 3, 0.01, 200, 300)
+    assert sum(out["basis_dictionary"].values()) > 512
+    assert np.array_equal(out["periods"], want["periods"]) and rel_err(out["norms"], want["norms"]) < TOL
+    assert list(out["basis_dictionary"].values()) == list(want["basis_dictionary"].values())
+    assert rel_err(out["weights"], want["weights"]) < 1e-7 and rel_err(res, wres) < 1e-7
+
+
+def test_qoperiods_orthogonal_selection(eng):
+    """find_periods(orthogonalize=True): raises TypeError in the v1 reference (best_base is never
+    assigned, QOPeriods.py:427-448); offered as the commented-out lines intend.  Expectation restated
+    from the oracle's pieces: period = argmax of the orthogonal powers of the residual, norm = gamma norm
+    of its orthogonalised projection, weights re-solved over the natural-basis dictionary."""
+    from pyperiod_amd import QOPeriods
+
+    sig = multi_sinusoid_window(12, 900)
+    got, res = QOPeriods(orthogonalize=True).find_periods(sig, num=3, thresh=0.05, max_length=200)
+    periods, norms, r = [], [], sig.copy()
+    for _ in range(3):
+        p = po.best_period_orthogonal(r, 200, True)
+        periods.append(p)
+        norms.append(po.periodic_norm(po.project(r, p, False, True), p))
+        a, dims = po.qo_get_subspaces(periods, sig.size)
+        w, rec = po.qo_solve_quadratic(sig, a)
+        r = sig - rec
+        rms = lambda v: np.sqrt(np.mean(v * v))  # noqa: E731
+        if not rms(rec) > rms(sig) * 0.05:
+            break
+    k = len(got["periods"])
+    assert k >= 2 and list(got["periods"]) == periods[:k]
+    assert rel_err(got["norms"], norms[:k]) < 1e-9
+
+
 def test_fp32_algorithms_track_the_fp64_oracle(eng):
     """fp32 windows through the whole algorithms (build-defined path, the reference has none):
     period lists must agree with the fp64 oracle on the fp32-rounded input for well-separated
@@ -360,6 +419,25 @@ def test_windows_longer_than_lds_stream_from_hbm(eng):
     assert np.array_equal(bper[0], rper) and rel_err(bnr[0], rnr) < TOL and rel_err(bbs[0], rbs) < TOL
     ram = eng.ramanujan_norms(x[:1], 2, 128)
     assert rel_err(ram[0], po.ramanujan_norms_folded(x[0], 2, 128)) < 1e-9
+    # the remaining entry points (missing 5): folds, orthogonal powers, best_frequency, QOPeriods
+    from pyperiod_amd import QOPeriods
+
+    a, dims = po.qo_get_subspaces([37, 64, 101], n)
+    folds = eng.fold_sums(x, [37, 64, 101], [37, 63, 100])
+    assert rel_err(folds, x @ a.T) < 1e-12
+    pows, ac, e3 = eng.orth_powers(x[:1], 400, True, want_autocorr=True, want_eq3=True)
+    assert rel_err(pows[0], po.orth_powers(x[0], 400, True)) < TOL
+    assert rel_err(ac[0, [0, 1, 7, 5000, n - 1]], [po.auto_corr(x[0], k) for k in (0, 1, 7, 5000, n - 1)]) < 1e-12
+    fper, fpw, fbs, fst = eng.best_frequency(x[:1], None, 2)
+    rper, rpw, rbs = po.best_frequency(x[0], None, 2)
+    assert fst[0] == 0 and np.array_equal(fper[0], rper) and rel_err(fpw[0], rpw) < TOL and rel_err(fbs[0], rbs) < TOL
+    fper, fpw, fbs, fst = eng.best_frequency(x[:1], None, 1, True, True)  # flagged projection of a long window
+    rper, rpw, rbs = po.best_frequency(x[0], None, 1, True, True)
+    assert np.array_equal(fper[0], rper) and rel_err(fbs[0], rbs) < TOL
+    out, res = QOPeriods().find_periods(x[0], num=2, thresh=0.1, min_length=8, max_length=200)
+    want, wres = po.qo_find_periods(x[0], 2, 0.1, 8, 200)
+    assert np.array_equal(out["periods"], want["periods"]) and rel_err(out["norms"], want["norms"]) < TOL
+    assert rel_err(out["weights"], want["weights"]) < 1e-8 and rel_err(res, wres) < 1e-8
 
 
 def test_batch_interface_edges(eng):
@@ -375,8 +453,6 @@ def test_batch_interface_edges(eng):
     nmax = eng.max_window()
     x = multi_sinusoid_batch(0, 1, nmax)
     assert np.array_equal(eng.project_batch(x, [977])[0, 0], po.project(x[0], 977))
-    with pytest.raises(ValueError):
-        eng.orth_powers(np.zeros((1, nmax + 4096)), 8)  # autocorrelation needs the window in LDS: PH_E_ARG
     with pytest.raises(ValueError):
         eng.project_batch(np.zeros((1, 8)), [0])
     with pytest.raises(ValueError):

@@ -68,7 +68,7 @@ def main():
             run(f"sweep_{nm}_1024x4096", lambda: eng.sweep(x4k, 2, 1365, mode), 1024 * 1364, "window_proj", 1024 * 1364 * 32768)
     if "s2l" in which:  # config 4, one GPU's shard
         x = torch.from_numpy(multi_sinusoid_batch(0, 8192, 4096)).to(dev)
-        run("c4_small_to_large_8192x4096", lambda: eng.small_to_large(x, 0.05, want_bases=False), 8192 * 2047, "window_proj", 8192 * 2047 * 32768)
+        run("c4_small_to_large_8192x4096", lambda: eng.small_to_large(x, 0.05, cap=32, want_bases=False, nosync=True), 8192 * 2047, "window_proj", 8192 * 2047 * 32768)
         del x
     if "bc" in which:
         run("best_correlation_num3_1024x4096", lambda: eng.best_correlation(x4k, 3), 1024 * 3 * 1363, "window_proj", 1024 * 3 * 1363 * 32768)
