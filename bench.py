@@ -168,8 +168,8 @@ def c2_workload():
     return f"config 2: m_best(num={NUM_PERIODS}) all-p sweep p=2..{N_SAMPLES // 3}, {WINDOWS_PER_GPU} windows x N={N_SAMPLES} fp64 per GPU"
 
 
-def c4_workload(world):
-    return (f"config 4: small_to_large(thresh={C4_THRESH}) p=2..{N_SAMPLES // 2}, {C4_WINDOWS} windows x N={N_SAMPLES} fp64, "
+def c4_workload(world, total=C4_WINDOWS):
+    return (f"config 4: small_to_large(thresh={C4_THRESH}) p=2..{N_SAMPLES // 2}, {total} windows x N={N_SAMPLES} fp64, "
             f"batch on rank 0 -> RCCL scatter -> compute on {world} GPU(s) -> RCCL gather")
 
 
@@ -429,7 +429,7 @@ def main():
                 "dtype": "f64",
                 "data": "synthetic (3 sinusoids + 5 % noise, numpy default_rng(1000 + w), SURVEY 8d)",
                 "config": {
-                    "workload": c4_workload(world),
+                    "workload": c4_workload(world, total),
                     "total_windows": total,
                     "n_samples": N_SAMPLES,
                     "periods_swept": N_SAMPLES // 2 - 1,

@@ -37,6 +37,13 @@ def _world(group=None):
     return 1, 0
 
 
+def _host_staged(group=None) -> bool:
+    """gloo moves host memory only (scatter / gather have no GPU path there): device tensors are
+    staged through the host.  Used by the CPU tests and by single-GPU rehearsals of the N > 1
+    code path; with backend nccl (RCCL) device buffers go straight over xGMI."""
+    return dist.get_backend(group) == "gloo"
+
+
 def _rows(x_root: torch.Tensor, lo: int, count: int, total: int) -> torch.Tensor:
     """Rows [lo, lo+count) of the root batch, zero-padded past `total` (only the pieces that
     straddle the end of the batch are copied; the others are views)."""
@@ -57,13 +64,14 @@ def scatter_windows(x_root, total: int, n: int, dtype, device, src: int = 0, gro
     if world == 1:
         return x_root.to(device)
     per = -(-total // world)
-    recv = torch.empty((per, n), dtype=dtype, device=device)
+    cdev = torch.device("cpu") if _host_staged(group) else device
+    recv = torch.empty((per, n), dtype=dtype, device=cdev)
     chunks = None
     if rank == src:
-        xr = x_root.to(device)
+        xr = x_root.to(cdev)
         chunks = [_rows(xr, r * per, per, total).contiguous() for r in range(world)]
     dist.scatter(recv, chunks, src=src, group=group)
-    return recv[: hi - lo]
+    return recv[: hi - lo].to(device)
 
 
 def gather_rows(local: torch.Tensor, total: int, dst: int = 0, group=None):
@@ -78,11 +86,13 @@ def gather_rows(local: torch.Tensor, total: int, dst: int = 0, group=None):
         pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], 0)
     send = send.contiguous()
+    if _host_staged(group):
+        send = send.cpu()
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat(bufs, 0)[:total]
+    return torch.cat(bufs, 0)[:total].to(local.device)
 
 
 def run_sharded(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, total: int, n: int, dtype, device,
@@ -112,13 +122,14 @@ def run_sharded_pipelined(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], 
     per = -(-total // world)
     pieces = max(1, min(int(pieces), per))
     step = -(-per // pieces)
-    xr = x_root.to(device) if rank == root else None
+    cdev = torch.device("cpu") if _host_staged(group) else device
+    xr = x_root.to(cdev) if rank == root else None
     recv, works = [], []
     for k in range(pieces):
         rows = min(step, per - k * step)
         if rows <= 0:
             break
-        buf = torch.empty((rows, n), dtype=dtype, device=device)
+        buf = torch.empty((rows, n), dtype=dtype, device=cdev)
         lists = None
         if rank == root:
             lists = [_rows(xr, r * per + k * step, rows, total).contiguous() for r in range(world)]
@@ -128,7 +139,7 @@ def run_sharded_pipelined(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], 
     for k, (buf, work) in enumerate(zip(recv, works)):
         work.wait()  # orders the current stream behind this piece only
         valid = max(0, min(hi - lo - k * step, buf.shape[0]))
-        outs.append(fn(buf[:valid]))
+        outs.append(fn(buf[:valid].to(device)))
     merged = [torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))]
     gathered = [gather_rows(o, total, root, group) for o in merged]
     return tuple(gathered) if rank == root else None
