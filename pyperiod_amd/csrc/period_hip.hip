@@ -77,6 +77,9 @@ struct ph_ctx {
   int plan_max_m = 4;  // largest row-class count a pass may use (PH_PLAN_MAX_M overrides: 1, 2 or 4)
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   int step1_block = 0;               // k_mbest_step1 only: 0 = automatic (PH_STEP1_BLOCK overrides, <= 1024)
+  int qo_block = 1024;               // k_qo_find threads per workgroup (PH_QO_BLOCK overrides)
+  int qo_panel = 0;                  // PH_QO_PANEL: cap on the Cholesky block width (0 = as wide as LDS allows, <= 32)
+  bool qo_hbm_window = false;        // PH_QO_HBM_WINDOW=1: keep the residual of k_qo_find in HBM even when it fits LDS
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
   int prof_n = 0;
@@ -399,24 +402,33 @@ using ph::kPad;
 using ph::kMaxWaves;
 using ph::kRedDoubles;
 
-// LDS layout of k_qo_find: everything but the Cholesky panel, then a panel as wide as the remaining
-// LDS allows (<= kQoPanelMax columns of kcap + 1 rows).
-int qo_lds_layout(ph_ctx* c, size_t sz, int N, int max_length, int kcap, size_t* lds_out, int* nbw_out) {
-  size_t lds = carve_bytes(N + kPad, sz) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
-               carve_bytes(kMaxWaves, 4) + 2 * carve_bytes(ph::kQoMaxBlocks, 4) +
-               carve_bytes(ph::kQoMaxBlocks + 1, 4) + carve_bytes(ph::kQoMaxBlocks, 8) +
-               carve_bytes((max_length + 32) / 32, 4) + carve_bytes(kcap, 8) +
-               carve_bytes((size_t)ph::kQoTile * ph::kQoPanelMax, 8) +
-               carve_bytes((size_t)kMaxWaves * ph::kQoPanelMax, 8);
-  PH_TRY(check_lds(c, lds, N, "ph_qo_find_periods"));
+// LDS layout of k_qo_find: bookkeeping, solve vector, then the block columns of the right-looking
+// Cholesky (pan_cap doubles: as many columns of K + 1 rows as fit, at most kQoNb).  The residual window
+// stays in LDS when at least `min_cols` columns of a full dictionary (kcap rows) fit beside it; otherwise
+// (long windows, large dictionaries) it moves to the HBM workspace and the sweeps read it through L2.
+int qo_lds_layout(ph_ctx* c, size_t sz, int N, int max_length, int kcap, size_t* lds_out, int* pan_cap_out,
+                  bool* lds_window_out) {
+  const size_t fixed = carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) +
+                       2 * carve_bytes(ph::kQoMaxBlocks, 4) + carve_bytes(ph::kQoMaxBlocks + 1, 4) +
+                       carve_bytes(ph::kQoMaxBlocks, 8) + carve_bytes((max_length + 32) / 32, 4) +
+                       carve_bytes(kcap, 8) + carve_bytes(ph::kQoNb, 8) + carve_bytes(4, 4);
+  const size_t win = carve_bytes(N + kPad, sz);
   const size_t ldp = (size_t)((kcap + 1) | 1);
-  const size_t room = (size_t)c->lds_limit > lds + 64 ? (size_t)c->lds_limit - lds - 64 : 0;
-  const int nbw = (int)std::min<size_t>(ph::kQoPanelMax, room / (ldp * 8));
-  if (nbw < 1)
-    return fail(PH_E_ARG, "ph_qo_find_periods: N=%d and kcap=%d leave no LDS for a Cholesky panel (limit %d B)", N,
-                kcap, c->lds_limit);
-  *lds_out = lds + carve_bytes(ldp * nbw, 8);
-  *nbw_out = nbw;
+  const size_t limit = (size_t)c->lds_limit;
+  auto columns = [&](size_t used) { return limit > used + 64 ? (limit - used - 64) / (ldp * 8) : 0; };
+  const size_t min_cols = 16;  // narrower blocks multiply the trailing-update traffic (K^3 / (3 nb) elements)
+  const bool lds_window = !c->qo_hbm_window && fixed + win <= limit && columns(fixed + win) >= min_cols;
+  const size_t used = fixed + (lds_window ? win : 0);
+  size_t cols = std::min<size_t>(columns(used), ph::kQoNb);
+  if (c->qo_panel) cols = std::min<size_t>(cols, (size_t)c->qo_panel);
+  if (cols < 1)
+    return fail(PH_E_ARG, "ph_qo_find_periods: kcap=%d leaves no LDS for a Cholesky block column (limit %d B)", kcap,
+                c->lds_limit);
+  // all the LDS that is left: smaller dictionaries (K < kcap) get wider blocks
+  const size_t pan_cap = c->qo_panel ? cols * ldp : (limit - used - 64) / 8;
+  *lds_out = used + carve_bytes(pan_cap, 8);
+  *pan_cap_out = (int)pan_cap;
+  *lds_window_out = lds_window;
   return PH_OK;
 }
 
@@ -478,6 +490,12 @@ int ph_create(int device, ph_ctx** out) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
   }
+  if (const char* e = std::getenv("PH_QO_BLOCK")) {
+    const int v = std::atoi(e);
+    if (v >= 64 && v <= 1024 && v % 64 == 0) c->qo_block = v;
+  }
+  if (std::getenv("PH_QO_HBM_WINDOW")) c->qo_hbm_window = true;
+  if (const char* e = std::getenv("PH_QO_PANEL")) c->qo_panel = std::max(1, std::min(32, std::atoi(e)));
   if (const char* e = std::getenv("PH_SWEEP_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 512 && v % 64 == 0) c->sweep_block = v;
@@ -1253,8 +1271,14 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   size_t lds;
-  int nbw;
-  PH_TRY(qo_lds_layout(c, sz, N, max_length, kcap, &lds, &nbw));
+  int pan_cap;
+  bool lds_window;
+  PH_TRY(qo_lds_layout(c, sz, N, max_length, kcap, &lds, &pan_cap, &lds_window));
+  void* gwin = nullptr;
+  if (!lds_window) {
+    PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * ph::win_stride(N + kPad) * sz));
+    gwin = c->buf[B_GWIN].p;
+  }
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, max_length, &geom));
   const ph::PassPlan* plan;
@@ -1277,7 +1301,7 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(upload_table(c, T_AUX0, phi.data(), phi.size(), &d_phi));
   PH_TRY(upload_table(c, T_AUX1, off.data(), off.size(), &d_off));
   PH_TRY(upload_table(c, T_AUX2, dq.data(), dq.size(), &d_dq));
-  const size_t ws_per = 2 * (size_t)kcap * kcap + 2 * (size_t)kcap;
+  const size_t ws_per = 2 * (size_t)kcap * kcap + 3 * (size_t)kcap;
   PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * ws_per * sizeof(double)));
   Stage st(c, flags);
   const void* dx;
@@ -1291,25 +1315,16 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(st.out(B_WS0, residual, (size_t)W * N * sz, &dres));
   PH_TRY(st.out(B_GEN0, status, (size_t)W * sizeof(int32_t), &dstat));
   const dim3 grid((unsigned)W);
-  if (dtype == PH_F64) {
-    PH_TRY(allow_lds(ph::k_qo_find<double>, lds));
-    {
-      ProfScope ps_(c, "k_qo_find");
-      hipLaunchKernelGGL(ph::k_qo_find<double>, grid, dim3(c->sweep_block), lds, c->stream, (const double*)dx, N, num,
-                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, nbw,
-                         (double*)c->buf[B_WS1].p, (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt,
-                         (double*)dwts, (double*)dres, (int*)dstat);
-    }
-  } else {
-    PH_TRY(allow_lds(ph::k_qo_find<float>, lds));
-    {
-      ProfScope ps_(c, "k_qo_find");
-      hipLaunchKernelGGL(ph::k_qo_find<float>, grid, dim3(c->sweep_block), lds, c->stream, (const float*)dx, N, num,
-                         thresh, min_length, max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, nbw,
-                         (double*)c->buf[B_WS1].p, (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt,
-                         (double*)dwts, (float*)dres, (int*)dstat);
-    }
-  }
+  PH_TRY(dispatch(dtype, lds_window, [&](auto t, auto lw) {
+    using T = decltype(t);
+    auto kernel = ph::k_qo_find<T, decltype(lw)::value>;
+    PH_TRY(allow_lds(kernel, lds));
+    ProfScope ps_(c, "k_qo_find");
+    hipLaunchKernelGGL(kernel, grid, dim3(c->qo_block), lds, c->stream, (const T*)dx, N, num, thresh, min_length,
+                       max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, pan_cap, (T*)gwin, (double*)c->buf[B_WS1].p,
+                       (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt, (double*)dwts, (T*)dres, (int*)dstat);
+    return (int)PH_OK;
+  }));
   PH_TRY(launch_check("k_qo_find"));
   return st.finish();
 }
@@ -1320,8 +1335,9 @@ int ph_qo_feasible(ph_ctx* c, int dtype, int N, int max_length, int kcap, int* o
   if (N < 1 || kcap < 1 || kcap > 2048) return PH_OK;
   if (max_length < 0) max_length = N / 3;
   size_t lds;
-  int nbw;
-  if (qo_lds_layout(c, elem_size(dtype), N, max_length, kcap, &lds, &nbw) == PH_OK) *ok = 1;
+  int pan_cap;
+  bool lds_window;
+  if (qo_lds_layout(c, elem_size(dtype), N, max_length, kcap, &lds, &pan_cap, &lds_window) == PH_OK) *ok = 1;
   return PH_OK;
 }
 

@@ -985,6 +985,9 @@ __global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, i
 //   One wavefront works on one root at a time; the wavefronts of a workgroup share the window.
 // ======================================================================================
 constexpr int kRamMaxWaves = 16;
+#ifndef PH_RAM_U
+#define PH_RAM_U 4
+#endif
 
 struct RamRoot {
   int q;       // root period, folded from the window
@@ -1143,11 +1146,13 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
       const int rows = geom[Q].rows, nfull = geom[Q].nfull;
       const int nchunks = (Q + 63) >> 6;
       int k0 = 0;
-      for (; k0 + 4 <= nchunks; k0 += 4) fold_store_group<T, 4, 2, LW>(xs, Q, rows, nfull, k0, lane, sA);
+      // LDS capacity (window + strips) caps this kernel at 3-4 wavefronts per SIMD, so registers are
+      // plentiful: PH_RAM_U rows x 4 chunks of loads in flight per wait
+      for (; k0 + 4 <= nchunks; k0 += 4) fold_store_group<T, 4, PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA);
       switch (nchunks - k0) {
-        case 3: fold_store_group<T, 3, 2, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
-        case 2: fold_store_group<T, 2, 4, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
-        case 1: fold_store_group<T, 1, 8, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
+        case 3: fold_store_group<T, 3, PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
+        case 2: fold_store_group<T, 2, 2 * PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
+        case 1: fold_store_group<T, 1, 4 * PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
         default: break;
       }
     }
@@ -1234,22 +1239,22 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 // ======================================================================================
 constexpr int kQoMaxBlocks = 64;
 
-constexpr int kQoPanelMax = 16;  // widest LDS panel of the blocked Cholesky
-constexpr int kQoTile = 64;      // finished columns staged per update step
+constexpr int kQoNb = 32;  // widest block of the right-looking Cholesky (columns held in LDS)
 
-template <typename T>
-__global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
+template <typename T, bool LW>
+__global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
                                                         int p_lo, int p_hi, const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
                                                         const int* __restrict__ phi, const int* __restrict__ div_off,
-                                                        const int* __restrict__ div_q, int kcap, int nbw,
+                                                        const int* __restrict__ div_q, int kcap, int pan_cap, T* gwin,
                                                         double* __restrict__ ws_all, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, int* __restrict__ keeps_out,
                                                         int* __restrict__ counts_out, double* __restrict__ weights_out,
                                                         T* __restrict__ resid_out, int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* work = cv.take<T>(N + kPad);  // the residual
+  // the residual: LDS, or (LW == false: long windows, or LDS given to the solver) the HBM workspace
+  T* work = window_buf<T, LW>(cv, gwin, N + kPad);
   double* red = cv.take<double>(kRedDoubles);
   double* wbest = cv.take<double>(kMaxWaves);
   int* wbestp = cv.take<int>(kMaxWaves);
@@ -1259,10 +1264,9 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
   double* bnorm = cv.take<double>(kQoMaxBlocks);
   uint32_t* seen = cv.take<uint32_t>((p_hi + 32) / 32);  // running divisor set R (QOPeriods.py:832-835)
   double* yv = cv.take<double>(kcap);  // solve vector
-  const int ldp = (kcap + 1) | 1;                                // panel column stride (odd: no bank conflicts)
-  double* pan = cv.take<double>((size_t)ldp * nbw);             // panel of the blocked factorisation
-  double* tile = cv.take<double>((size_t)kQoTile * kQoPanelMax);  // block row of L for the panel update
-  double* dsum = cv.take<double>((size_t)kMaxWaves * kQoPanelMax);
+  double* dsum = cv.take<double>(kQoNb);
+  int* sing_flag = cv.take<int>(4);
+  double* pan = cv.take<double>((size_t)pan_cap);  // block columns of the factorisation (stride (K + 1) | 1, odd)
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1270,9 +1274,9 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const T* data = x + w * (int64_t)N;
-  double* G = ws_all + w * (2 * (int64_t)kcap * kcap + 2 * (int64_t)kcap);  // Gram, column-major, ld = kcap
-  double* L = G + (int64_t)kcap * kcap;                                      // Cholesky factor
-  double* rhs = L + (int64_t)kcap * kcap;
+  double* G = ws_all + w * (2 * (int64_t)kcap * kcap + 3 * (int64_t)kcap);  // Gram, column-major, ld = kcap
+  double* L = G + (int64_t)kcap * kcap;                                      // Cholesky factor, ld = kcap + 1
+  double* rhs = L + (int64_t)(kcap + 1) * kcap;
   double* wts = rhs + kcap;  // last good weights
 
   load_window(data, work, N);
@@ -1286,6 +1290,18 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
   int status = 0;
   bool stopped_by_test = false;
 
+#ifdef PH_QO_TIMERS
+  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq0 = wall_clock64();
+#define PH_QO_MARK(k)                         \
+  {                                           \
+    const long long now_ = wall_clock64();    \
+    tq[k] += now_ - tq0;                      \
+    tq0 = now_;                               \
+  }
+#else
+#define PH_QO_MARK(k)
+#endif
   for (int it = 0; it < num; ++it) {
     if (it > 0 && !(sqrt(recon_sq / N) > sqrt(data_sq / N) * thresh)) {  // QOPeriods.py:391,418
       stopped_by_test = true;
@@ -1299,7 +1315,7 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     double best = 0.0;
     int bestp = 0;
     double best_ss = 0.0;  // same lazy comparison as in k_mbest_step1 (gamma norm: ss / p)
-    wave_sweep_plan<T, true>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
+    wave_sweep_plan<T, LW>(work, N, geom, plan, wv, n_pass, nw, lane, [&](double ss, int p) {
       if (!(ss > 0.0)) return;
       bool take = bestp == 0;
       if (!take) {
@@ -1335,6 +1351,7 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
       }
     }
     __syncthreads();
+    PH_QO_MARK(0)
     if (bestp == 0) break;  // nothing left to explain; the reference keeps looping on zeros
     // ---- rows this period contributes (QOPeriods.py:833-840); a repeated period or one whose
     //      divisors are all present adds none and makes the reference's matrix singular
@@ -1389,6 +1406,7 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
         }
       }
     }
+    PH_QO_MARK(1)
     // right-hand side: fold of the data (QOPeriods.py:782), one wavefront per residue (a small period
     // has few residues with many samples each: two threads summing 8192 samples cost 0.2 ms)
     for (int j = wv; j < keep; j += nw) {
@@ -1400,6 +1418,7 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     }
     __threadfence_block();
     __syncthreads();
+    PH_QO_MARK(2)
     // mirror the new columns into the old columns' new rows
     for (int e = tid; e < row0 * keep; e += blockDim.x) {
       const int r = e % row0, j = e / row0;
@@ -1407,121 +1426,185 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     }
     __threadfence_block();
     __syncthreads();
-    // ---- G = L L^T, L y = rhs, L^T w = y.  Blocked left-looking Cholesky of the augmented matrix
-    //      [G rhs; rhs^T .] (its last row is y): a panel of <= nbw columns (rows J..K-1 plus the rhs
-    //      row) lives in LDS, the finished columns are streamed from the HBM workspace once per panel
-    //      (coalesced, read-only), and the panel itself is factored at LDS speed.
+    PH_QO_MARK(3)
+    // ---- G = L L^T, L y = rhs, L^T w = y.  Right-looking blocked Cholesky of the augmented matrix
+    //      [G; rhs^T] (the rhs is carried as row K of every column, it leaves the factorisation as y):
+    //      the lower triangle is copied into the factor workspace and reduced in place, a block of <= NB
+    //      columns at a time.  The block's columns (all rows below the diagonal) sit in LDS: one wavefront
+    //      factors the diagonal block, every thread then solves one row against it in registers, and the
+    //      trailing matrix is updated in a single sweep -- every element read and written once per block,
+    //      4 columns x 2 rows per lane, coalesced -- so the work per step is K^2 / 2 independent elements
+    //      instead of one narrow panel.
     bool singular = false;
-    for (int J = 0; J < K && !singular; J += nbw) {
-      const int jb = min(nbw, K - J);
-      const int nr = K - J + 1;  // rows J .. K-1 and the rhs row
-      for (int e = tid; e < nr * jb; e += blockDim.x) {
-        const int cc = e / nr, rr = e % nr, r = J + rr;
-        pan[cc * ldp + rr] = r < K ? (rr >= cc ? G[(int64_t)(J + cc) * kcap + r] : 0.0) : rhs[J + cc];
+    {
+      const int ldl = kcap + 1;  // factor workspace: column-major, rows 0..K-1 then the rhs row
+      const int ldp = (K + 1) | 1;
+      const int nbmax = min(kQoNb, pan_cap / ldp);
+      for (int e = tid; e < K * (K + 1); e += blockDim.x) {
+        const int c = e / (K + 1), r = e - c * (K + 1);
+        if (r >= c) L[(int64_t)c * ldl + r] = r < K ? G[(int64_t)c * kcap + r] : rhs[c];
       }
+      if (tid == 0) *sing_flag = 0;
+      __threadfence_block();
       __syncthreads();
-      for (int t0 = 0; t0 < J; t0 += kQoTile) {
-        const int tn = min(kQoTile, J - t0);
-        for (int e = tid; e < tn * kQoPanelMax; e += blockDim.x) {
-          const int tt = e / kQoPanelMax, cc = e % kQoPanelMax;
-          tile[e] = cc < jb ? L[(int64_t)(t0 + tt) * kcap + J + cc] : 0.0;
+      for (int J = 0; J < K; J += nbmax) {
+        const int jb = min(nbmax, K - J);
+        const int nr = K - J + 1;  // rows J .. K-1 and the rhs row
+        for (int e = tid; e < nr * jb; e += blockDim.x) {
+          const int cc = e / nr, rr = e - cc * nr;
+          pan[cc * ldp + rr] = rr >= cc ? L[(int64_t)(J + cc) * ldl + J + rr] : 0.0;
         }
         __syncthreads();
-        for (int rr = tid; rr < nr; rr += blockDim.x) {
-          double acc[kQoPanelMax];
-#pragma unroll
-          for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = 0.0;
-          const bool is_rhs = rr == nr - 1;
-          const double* src = is_rhs ? yv + t0 : L + (int64_t)t0 * kcap + J + rr;
-          const int64_t stride = is_rhs ? 1 : kcap;
-          int tt = 0;
-          for (; tt + 8 <= tn; tt += 8) {  // eight independent HBM loads in flight, then their fma (16 was slower)
-            double a[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = src[(tt + u) * stride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-              for (int cc = 0; cc < kQoPanelMax; ++cc)
-                acc[cc] = fma(a[u], tile[(tt + u) * kQoPanelMax + cc], acc[cc]);
+        if (wv == 0) {  // diagonal block jb x jb, one wavefront, lane = row
+          for (int cc = 0; cc < jb; ++cc) {
+            const double piv = pan[cc * ldp + cc];
+            if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
+              if (lane == 0) *sing_flag = 1;
+              break;
+            }
+            const double d = sqrt(piv);
+            for (int r = cc + lane; r < jb; r += kWave) pan[cc * ldp + r] = r == cc ? d : pan[cc * ldp + r] / d;
+            ram_wave_sync();
+            for (int c2 = cc + 1; c2 < jb; ++c2) {
+              const double f = pan[cc * ldp + c2];
+              for (int r = c2 + lane; r < jb; r += kWave) pan[c2 * ldp + r] -= pan[cc * ldp + r] * f;
+            }
+            ram_wave_sync();
           }
-          for (; tt < tn; ++tt) {
-            const double a = src[tt * stride];
-#pragma unroll
-            for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = fma(a, tile[tt * kQoPanelMax + cc], acc[cc]);
-          }
-#pragma unroll
-          for (int cc = 0; cc < kQoPanelMax; ++cc)
-            if (cc < jb) pan[cc * ldp + rr] -= acc[cc];
         }
         __syncthreads();
-      }
-      for (int cc = 0; cc < jb; ++cc) {
-        const double piv = pan[cc * ldp + cc];
-        if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
+        if (*sing_flag) {
           singular = true;
           break;
         }
-        const double d = sqrt(piv);
-        __syncthreads();
-        for (int rr = cc + tid; rr < nr; rr += blockDim.x) pan[cc * ldp + rr] /= d;
-        __syncthreads();
-        const int span = nr - cc - 1;
-        for (int e = tid; e < (jb - cc - 1) * span; e += blockDim.x) {
-          const int c2 = cc + 1 + e / span, rr = cc + 1 + e % span;
-          if (rr >= c2) pan[c2 * ldp + rr] -= pan[cc * ldp + rr] * pan[cc * ldp + c2];
+        // rows below the block (and the rhs row): x D^T = a, forward substitution, 16 columns at a time in
+        // registers (the earlier columns of the row are read back from the panel)
+        for (int rr = jb + tid; rr < nr; rr += blockDim.x) {
+#pragma unroll 1
+          for (int c_lo = 0; c_lo < jb; c_lo += 16) {
+            double xr[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int cc = c_lo + u;
+              if (cc < jb) {
+                double v = pan[cc * ldp + rr];
+                for (int c2 = 0; c2 < c_lo; ++c2) v = fma(-pan[c2 * ldp + rr], pan[c2 * ldp + cc], v);
+#pragma unroll
+                for (int u2 = 0; u2 < u; ++u2) v = fma(-xr[u2], pan[(c_lo + u2) * ldp + cc], v);
+                xr[u] = v / pan[cc * ldp + cc];
+              } else {
+                xr[u] = 0.0;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+              if (c_lo + u < jb) pan[(c_lo + u) * ldp + rr] = xr[u];
+          }
         }
         __syncthreads();
-      }
-      if (singular) break;
-      for (int e = tid; e < nr * jb; e += blockDim.x) {
-        const int cc = e / nr, rr = e % nr, r = J + rr;
-        if (rr >= cc) {
-          if (r < K)
-            L[(int64_t)(J + cc) * kcap + r] = pan[cc * ldp + rr];
-          else
-            yv[J + cc] = pan[cc * ldp + rr];
+        for (int e = tid; e < nr * jb; e += blockDim.x) {
+          const int cc = e / nr, rr = e - cc * nr;
+          if (rr >= cc) {
+            if (rr < nr - 1)
+              L[(int64_t)(J + cc) * ldl + J + rr] = pan[cc * ldp + rr];
+            else
+              yv[J + cc] = pan[cc * ldp + rr];
+          }
         }
+        // trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for j >= J + jb, j <= i <= K
+        const int T0 = J + jb;
+        const int ngroups = (K - T0 + 3) >> 2;  // 4 columns per item
+        for (int item = wv;; item += nw) {
+          // items: (column group g, 128-row chunk h) with rows from the group's first diagonal element
+          int g = 0, h = item;
+          // chunks per group shrink with g; walk the (short) list: groups have ceil((K + 1 - j0) / 128) chunks
+          bool found = false;
+          for (; g < ngroups; ++g) {
+            const int j0g = T0 + 4 * g;
+            const int nch = (K + 1 - j0g + 127) >> 7;
+            if (h < nch) {
+              found = true;
+              break;
+            }
+            h -= nch;
+          }
+          if (!found) break;
+          const int j0 = T0 + 4 * g;
+          const int i0 = j0 + 128 * h + lane;  // rows i0, i0 + 64
+          double acc[2][4];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[k][q] = 0.0;
+          const int ra = min(i0 - J, nr - 1), rb = min(i0 + 64 - J, nr - 1);  // clamped panel rows (masked on store)
+          const int cj = j0 - J;
+          for (int c = 0; c < jb; ++c) {
+            const double* col = pan + c * ldp;
+            const double pa = col[ra], pb = col[rb];
+            double pj[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pj[q] = col[min(cj + q, nr - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc[0][q] = fma(pa, pj[q], acc[0][q]);
+              acc[1][q] = fma(pb, pj[q], acc[1][q]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int jq = j0 + q;
+            if (jq < K) {
+              double* dst = L + (int64_t)jq * ldl;
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                const int i = i0 + 64 * k;
+                if (i >= jq && i <= K) dst[i] -= acc[k][q];
+              }
+            }
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
       }
-      __threadfence_block();
-      __syncthreads();
     }
+    PH_QO_MARK(4)
     if (singular) break;  // go back one iteration and stop (QOPeriods.py:552-559)
-    // L^T w = y, panels from the last one back: the rows below a panel are already final, their
-    // contribution is one workgroup reduction per panel; the diagonal block is solved by thread 0
-    for (int jend = K; jend > 0;) {
-      const int jb = min(nbw, jend), J = jend - jb, nr = K - J;
-      for (int e = tid; e < nr * jb; e += blockDim.x) {
-        const int cc = e / nr, rr = e % nr;
-        if (rr >= cc) pan[cc * ldp + rr] = L[(int64_t)(J + cc) * kcap + J + rr];
-      }
-      __syncthreads();
-      double acc[kQoPanelMax];
-#pragma unroll
-      for (int cc = 0; cc < kQoPanelMax; ++cc) acc[cc] = 0.0;
-      for (int rr = jb + tid; rr < nr; rr += blockDim.x) {
-        const double wr = yv[J + rr];
-#pragma unroll
-        for (int cc = 0; cc < kQoPanelMax; ++cc)
-          if (cc < jb) acc[cc] = fma(pan[cc * ldp + rr], wr, acc[cc]);
-      }
-#pragma unroll
-      for (int cc = 0; cc < kQoPanelMax; ++cc) {
-        const double v = wave_sum(acc[cc]);
-        if (lane == 0) dsum[wv * kQoPanelMax + cc] = v;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        for (int cc = jb - 1; cc >= 0; --cc) {
-          double v = yv[J + cc];
-          for (int i = 0; i < nw; ++i) v -= dsum[i * kQoPanelMax + cc];
-          for (int c2 = cc + 1; c2 < jb; ++c2) v -= pan[cc * ldp + c2] * yv[J + c2];
-          yv[J + cc] = v / pan[cc * ldp + cc];
+    // L^T w = y, blocks from the last one back: the rows below a block are already final -- their
+    // contribution is one wavefront dot product per column --, the diagonal block is solved by one wavefront
+    {
+      const int ldl = kcap + 1;
+      const int ldp = (K + 1) | 1;
+      const int nbmax = min(kQoNb, pan_cap / ldp);
+      for (int jend = K; jend > 0;) {
+        const int jb = min(nbmax, jend), J = jend - jb, nr = K - J;
+        for (int e = tid; e < nr * jb; e += blockDim.x) {
+          const int cc = e / nr, rr = e - cc * nr;
+          if (rr >= cc) pan[cc * ldp + rr] = L[(int64_t)(J + cc) * ldl + J + rr];
         }
+        __syncthreads();
+        for (int cc = wv; cc < jb; cc += nw) {
+          double a = 0.0;
+          for (int rr = jb + lane; rr < nr; rr += kWave) a = fma(pan[cc * ldp + rr], yv[J + rr], a);
+          a = wave_sum(a);
+          if (lane == 0) dsum[cc] = a;
+        }
+        __syncthreads();
+        if (wv == 0) {  // lane c carries v_c = y_c - (solved part); solutions appear from the last row up
+          double v = lane < jb ? yv[J + lane] - dsum[lane] : 0.0;
+          for (int cc = jb - 1; cc >= 0; --cc) {
+            const double wc = __shfl(v, cc, kWave) / pan[cc * ldp + cc];
+            if (lane == cc)
+              v = wc;
+            else if (lane < cc)
+              v = fma(-pan[lane * ldp + cc], wc, v);
+          }
+          if (lane < jb) yv[J + lane] = v;
+        }
+        __syncthreads();
+        jend = J;
       }
-      __syncthreads();
-      jend = J;
     }
+    PH_QO_MARK(5)
     nb += 1;
     // ---- reconstruction A^T w (QOPeriods.py:795) and the new residual
     double rs = 0.0;
@@ -1537,8 +1620,14 @@ __global__ __launch_bounds__(kBlockWide) void k_qo_find(const T* __restrict__ x,
     for (int r = tid; r < K; r += blockDim.x) wts[r] = yv[r];
     recon_sq = block_sum(rs, red);
     __syncthreads();
+    PH_QO_MARK(6)
   }
   __syncthreads();
+#ifdef PH_QO_TIMERS
+  if (w < 12 && tid == 0)
+    printf("qo timers (100 MHz ticks) sweep %lld gram %lld rhs %lld mirror %lld chol %lld backsub %lld recon %lld  K=%d nb=%d\n",
+           tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], boff[nb], nb);
+#endif
   // outputs.  When the loop stopped on the test function the reference reports all periods
   // but the last one, yet keeps the weights / dictionary of all of them (QOPeriods.py:584-592).
   const int n_report = stopped_by_test ? nb - 1 : nb;

@@ -281,6 +281,27 @@ def test_qoperiods_falls_back_to_the_host_loop(eng):
     assert rel_err(out["weights"], want["weights"]) < 1e-7 and rel_err(res, wres) < 1e-7
 
 
+def test_qoperiods_host_driven_variants(eng):
+    """The host-driven greedy loop (custom test function, update_weights=False) against the oracle /
+    the single-launch kernel: same periods, norms, dictionary and weights."""
+    from pyperiod_amd import QOPeriods
+    from pyperiod_amd.Periods import rms
+
+    sig = multi_sinusoid_window(5, 1536)
+    dev_out, dev_res = QOPeriods().find_periods(sig, num=4, thresh=0.2, min_length=4, max_length=200)
+    host_out, host_res = QOPeriods().find_periods(sig, num=4, thresh=0.2, min_length=4, max_length=200,
+                                                  test_function=lambda self, x, y: rms(y) > rms(x) * 0.2)
+    assert np.array_equal(dev_out["periods"], host_out["periods"]) and rel_err(host_out["norms"], dev_out["norms"]) < TOL
+    assert dev_out["basis_dictionary"] == host_out["basis_dictionary"]
+    assert rel_err(host_out["weights"], dev_out["weights"]) < 1e-8 and rel_err(host_res, dev_res) < 1e-8
+    assert host_out["subspaces"].shape == dev_out["subspaces"].shape
+    # update_weights=False (QOPeriods.py:645-714; overflows under numpy 2 in the v1 reference): every new period
+    # is fitted to the running residual only, so the residual energy never grows and the weights concatenate
+    out, res = QOPeriods().find_periods(sig, num=3, thresh=0.05, min_length=4, max_length=200, update_weights=False)
+    assert len(out["periods"]) >= 2 and out["weights"].size == sum(out["basis_dictionary"].values())
+    assert po.periodic_norm(res) < po.periodic_norm(sig)
+
+
 def test_qoperiods_orthogonal_selection(eng):
     """find_periods(orthogonalize=True): raises TypeError in the v1 reference (best_base is never
     assigned, QOPeriods.py:427-448); offered as the commented-out lines intend.  Expectation restated
