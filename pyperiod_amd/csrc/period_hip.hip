@@ -132,7 +132,7 @@ size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
 // Pass plan of a norm sweep over [p_lo, p_hi]: every period is produced exactly once, either
 // by its own pass or as 2p / 4p of a smaller base period (see PassPlan in ph_device.h).
 // Periods below 64 use the row-split path one at a time (m = 0).
-std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m) {
+std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m, bool mixed = true) {
   std::vector<ph::PassPlan> host;
   std::vector<char> covered((size_t)p_hi + 1, 0);
   for (int p = p_lo; p <= p_hi; ++p) {
@@ -149,7 +149,7 @@ std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m) {
   // Interleave the pass types evenly (entry i of a type with n entries gets the key (i + 0.5) / n):
   // the waves of a CU walk the plan in step, and a mix of LDS-heavy single passes and VALU-heavy
   // multi-class passes overlaps better than a phase of each.
-  if (!std::getenv("PH_PLAN_SORTED")) {
+  if (mixed && !std::getenv("PH_PLAN_SORTED")) {
     int count[5] = {0, 0, 0, 0, 0}, seen[5] = {0, 0, 0, 0, 0};
     for (const auto& e : host) count[e.m] += 1;
     std::vector<std::pair<double, size_t>> key(host.size());
@@ -173,14 +173,19 @@ std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m) {
   return host;
 }
 
-int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4) {
+// `mixed`: interleave the pass types (kernels whose workgroups split the plan in chunks: a mix of LDS-heavy
+// and VALU-heavy passes overlaps better); otherwise ascending base period, i.e. the expensive multi-class
+// passes first and the cheap few-row singles last -- what a workgroup that walks the WHOLE plan between two
+// barriers wants (k_mbest_step1: shorter tail before the argmax barrier, -3 %).
+int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4, bool mixed = true) {
   max_m = std::min(max_m, c->plan_max_m);
+  if (!mixed) max_m += 8;  // cache key
   if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi && c->plan_m == max_m) {
     *out = static_cast<const ph::PassPlan*>(c->plan.p);
     *n_pass = c->plan_n;
     return PH_OK;
   }
-  const std::vector<ph::PassPlan> host = build_plan(p_lo, p_hi, max_m);
+  const std::vector<ph::PassPlan> host = build_plan(p_lo, p_hi, mixed ? max_m : max_m - 8, mixed);
   PH_HIP(hipStreamSynchronize(c->stream));
   PH_TRY(ensure(c, c->plan, std::max<size_t>(1, host.size()) * sizeof(ph::PassPlan)));
   if (!host.empty())
@@ -746,7 +751,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   PH_TRY(prepare_geom(c, N, max_length, &geom));
   const ph::PassPlan* plan;
   int n_pass;
-  PH_TRY(prepare_plan(c, min_length, max_length, &plan, &n_pass));
+  PH_TRY(prepare_plan(c, min_length, max_length, &plan, &n_pass, 4, false));
   Stage st(c, flags);
   const void* dx;
   void *dper, *dpow, *dbases, *dstat;
@@ -928,7 +933,12 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   PH_TRY(check_lds(c, lds, N, "ph_best_frequency"));
   const size_t lds_spec = (lds_window ? carve_bytes(N, sz) : 0) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
   PH_TRY(check_lds(c, lds_spec, N, "ph_best_frequency"));
-  const int nchunk = (L / 2 + 1 + ph::kBfBlock - 1) / ph::kBfBlock;
+  // power-of-two win_size whose complex work array fits the LDS: in-LDS FFT, one record per window
+  const size_t lds_fft = 2 * carve_bytes(L, 8) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+  const bool use_fft = (L & (L - 1)) == 0 && L >= 4 && lds_fft <= (size_t)c->lds_limit && !std::getenv("PH_BF_DIRECT");
+  int logL = 0;
+  while ((1 << logL) < L) ++logL;
+  const int nchunk = use_fft ? 1 : (L / 2 + 1 + ph::kBfBlock - 1) / ph::kBfBlock;
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, 2 * L, &tb));
   if (c->twid_len != L) {  // twiddles in float64; k / L is an exact fraction of a turn
@@ -969,9 +979,14 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
     using T = decltype(t);
     constexpr bool LW = decltype(lw)::value;
     PH_TRY(allow_lds(ph::k_bf_spectrum<T, LW>, lds_spec));
+    if (use_fft) PH_TRY(allow_lds(ph::k_bf_fft<T>, lds_fft));
     PH_TRY(allow_lds(ph::k_bf_update<T, LW>, lds));
     for (int it = 0; it < num; ++it) {
-      {
+      if (use_fft) {
+        ProfScope ps_(c, "k_bf_fft");
+        hipLaunchKernelGGL((ph::k_bf_fft<T>), grid_u, dim3(kBlockWide), lds_fft, c->stream, (const T*)dres, N, L, logL,
+                           (const double2*)c->twid.p, (const int*)dstat, dpart, dpartk);
+      } else {
         ProfScope ps_(c, "k_bf_spectrum");
         hipLaunchKernelGGL((ph::k_bf_spectrum<T, LW>), grid_s, dim3(ph::kBfBlock), lds_spec, c->stream, (const T*)dres, N, L,
                            (const double2*)c->twid.p, (const int*)dstat, dpart, dpartk);

@@ -893,6 +893,78 @@ __global__ __launch_bounds__(kBfBlock) void k_bf_spectrum(const T* __restrict__ 
   }
 }
 
+// Power-of-two win_size that fits the LDS: the spectrum is an in-LDS radix-2 FFT (decimation in time,
+// bit-reversed load, log2 L stages of L / 2 butterflies, twiddles from the same float64 table), one
+// workgroup per window -- O(L log L) instead of the O(N L) of the direct DFT above.  Leaves the same
+// (|X|^2, bin + 1) record, first maximum, in chunk slot 0.
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_bf_fft(const T* __restrict__ res, int N, int L, int logL,
+                                                       const double2* __restrict__ tw,
+                                                       const int* __restrict__ status,
+                                                       double* __restrict__ part_m2, int* __restrict__ part_k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  double* re = cv.take<double>(L);
+  double* im = cv.take<double>(L);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  const int64_t w = blockIdx.x;
+  if (status[w] != 0) return;  // the reference has raised for this window already
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int M = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
+  const T* xs = res + w * (int64_t)N;
+  for (int n = tid; n < L; n += blockDim.x) {
+    const int r = (int)(__brev((unsigned)n) >> (32 - logL));
+    re[r] = n < M ? (double)xs[n] : 0.0;
+    im[r] = 0.0;
+  }
+  __syncthreads();
+  for (int s = 1; s <= logL; ++s) {
+    const int half = 1 << (s - 1);
+    const int tstep = L >> s;  // twiddle index step: exp(-2 pi i j / 2^s) = conj(tw[j * L / 2^s])
+    for (int b = tid; b < (L >> 1); b += blockDim.x) {
+      const int j = b & (half - 1);
+      const int a0 = ((b >> (s - 1)) << s) + j, a1 = a0 + half;
+      const double2 cs = tw[j * tstep];  // (cos, sin) of +angle; the forward transform uses cos - i sin
+      const double xr = re[a1], xi = im[a1];
+      const double tr = fma(xr, cs.x, xi * cs.y), ti = fma(xi, cs.x, -xr * cs.y);
+      const double ur = re[a0], ui = im[a0];
+      re[a0] = ur + tr;
+      im[a0] = ui + ti;
+      re[a1] = ur - tr;
+      im[a1] = ui - ti;
+    }
+    __syncthreads();
+  }
+  double best = -1.0;
+  int bestk = 0;  // bin + 1; 0 = none
+  for (int k = tid; k <= (L >> 1); k += blockDim.x) {
+    const double m2 = re[k] * re[k] + im[k] * im[k];
+    if (m2 > best) {  // false for NaN; ascending k per thread keeps the first maximum
+      best = m2;
+      bestk = k + 1;
+    }
+  }
+  wave_argmax(best, bestk);
+  if (lane == 0) {
+    wbest[wv] = best;
+    wbestp[wv] = bestk;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    best = -1.0;
+    bestk = 0;
+    for (int i = 0; i < nw; ++i)
+      if (wbestp[i] != 0 && (bestk == 0 || wbest[i] > best || (wbest[i] == best && wbestp[i] < bestk))) {
+        best = wbest[i];
+        bestk = wbestp[i];
+      }
+    part_m2[w] = best;
+    part_k[w] = bestk;
+  }
+}
+
 template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) void k_bf_update(T* __restrict__ res, int N, int L, int num, int it,
                                                           unsigned flags, Tables tb, T* __restrict__ gbuf, int nchunk,
