@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
   bool stopped_by_test = false;
 
 #ifdef PH_QO_TIMERS
-  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tq0 = wall_clock64();
 #define PH_QO_MARK(k)                         \
   {                                           \
@@ -1519,6 +1519,7 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
       if (tid == 0) *sing_flag = 0;
       __threadfence_block();
       __syncthreads();
+      PH_QO_MARK(8)
       for (int J = 0; J < K; J += nbmax) {
         const int jb = min(nbmax, K - J);
         const int nr = K - J + 1;  // rows J .. K-1 and the rhs row
@@ -1527,30 +1528,46 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
           pan[cc * ldp + rr] = rr >= cc ? L[(int64_t)(J + cc) * ldl + J + rr] : 0.0;
         }
         __syncthreads();
-        if (wv == 0) {  // diagonal block jb x jb, one wavefront, lane = row
+        PH_QO_MARK(9)
+        if (wv == 0) {  // diagonal block jb x jb (jb <= 32), one wavefront, lane = row, left-looking:
+          // column cc of row r is a dot product over the finished columns -- reads only, no
+          // read-modify-write chains through LDS
           for (int cc = 0; cc < jb; ++cc) {
-            const double piv = pan[cc * ldp + cc];
+            const bool act = lane >= cc && lane < jb;
+            double v = 0.0;
+            if (act) {
+              v = pan[cc * ldp + lane];
+              int c2 = 0;
+              for (; c2 + 8 <= cc; c2 += 8) {  // eight independent pairs of LDS reads per wait
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  a[u] = pan[(c2 + u) * ldp + lane];
+                  b[u] = pan[(c2 + u) * ldp + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v = fma(-a[u], b[u], v);
+              }
+              for (; c2 < cc; ++c2) v = fma(-pan[c2 * ldp + lane], pan[c2 * ldp + cc], v);
+            }
+            const double piv = __shfl(v, cc, kWave);
             if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
               if (lane == 0) *sing_flag = 1;
               break;
             }
             const double d = sqrt(piv);
-            for (int r = cc + lane; r < jb; r += kWave) pan[cc * ldp + r] = r == cc ? d : pan[cc * ldp + r] / d;
-            ram_wave_sync();
-            for (int c2 = cc + 1; c2 < jb; ++c2) {
-              const double f = pan[cc * ldp + c2];
-              for (int r = c2 + lane; r < jb; r += kWave) pan[c2 * ldp + r] -= pan[cc * ldp + r] * f;
-            }
+            if (act) pan[cc * ldp + lane] = lane == cc ? d : v / d;
             ram_wave_sync();
           }
         }
         __syncthreads();
+        PH_QO_MARK(10)
         if (*sing_flag) {
           singular = true;
           break;
         }
         // rows below the block (and the rhs row): x D^T = a, forward substitution, 16 columns at a time in
-        // registers (the earlier columns of the row are read back from the panel)
+        // registers; the finished half is folded into the columns of the second half before it is dropped
         for (int rr = jb + tid; rr < nr; rr += blockDim.x) {
 #pragma unroll 1
           for (int c_lo = 0; c_lo < jb; c_lo += 16) {
@@ -1560,7 +1577,6 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
               const int cc = c_lo + u;
               if (cc < jb) {
                 double v = pan[cc * ldp + rr];
-                for (int c2 = 0; c2 < c_lo; ++c2) v = fma(-pan[c2 * ldp + rr], pan[c2 * ldp + cc], v);
 #pragma unroll
                 for (int u2 = 0; u2 < u; ++u2) v = fma(-xr[u2], pan[(c_lo + u2) * ldp + cc], v);
                 xr[u] = v / pan[cc * ldp + cc];
@@ -1571,9 +1587,16 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
 #pragma unroll
             for (int u = 0; u < 16; ++u)
               if (c_lo + u < jb) pan[(c_lo + u) * ldp + rr] = xr[u];
+            for (int cc = c_lo + 16; cc < jb; ++cc) {  // 16 independent broadcast reads per column
+              double t = pan[cc * ldp + rr];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) t = fma(-xr[u], pan[(c_lo + u) * ldp + cc], t);
+              pan[cc * ldp + rr] = t;
+            }
           }
         }
         __syncthreads();
+        PH_QO_MARK(11)
         for (int e = tid; e < nr * jb; e += blockDim.x) {
           const int cc = e / nr, rr = e - cc * nr;
           if (rr >= cc) {
@@ -1583,60 +1606,75 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
               yv[J + cc] = pan[cc * ldp + rr];
           }
         }
+        PH_QO_MARK(12)
         // trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for j >= J + jb, j <= i <= K
         const int T0 = J + jb;
         const int ngroups = (K - T0 + 3) >> 2;  // 4 columns per item
-        for (int item = wv;; item += nw) {
-          // items: (column group g, 128-row chunk h) with rows from the group's first diagonal element
-          int g = 0, h = item;
-          // chunks per group shrink with g; walk the (short) list: groups have ceil((K + 1 - j0) / 128) chunks
-          bool found = false;
-          for (; g < ngroups; ++g) {
-            const int j0g = T0 + 4 * g;
-            const int nch = (K + 1 - j0g + 127) >> 7;
-            if (h < nch) {
-              found = true;
-              break;
-            }
-            h -= nch;
-          }
-          if (!found) break;
+        const int maxch = (K + 1 - T0 + 127) >> 7;  // 128-row chunks of the longest (first) column group
+        // items: (column group g, chunk h) with rows from the group's first diagonal element; later groups
+        // have fewer chunks, their surplus items fall through
+        for (int item = wv; item < ngroups * maxch; item += nw) {
+          const int g = item / maxch, h = item - g * maxch;
+          if (128 * h > K - (T0 + 4 * g)) continue;
           const int j0 = T0 + 4 * g;
           const int i0 = j0 + 128 * h + lane;  // rows i0, i0 + 64
+          // the old values are requested first: their HBM / L2 latency hides behind the dot products
           double acc[2][4];
+          bool ok[2][4];
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
+          for (int q = 0; q < 4; ++q) {
+            const int jq = j0 + q;
+            const double* src = L + (int64_t)min(jq, K - 1) * ldl;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[k][q] = 0.0;
+            for (int k = 0; k < 2; ++k) {
+              const int i = i0 + 64 * k;
+              ok[k][q] = jq < K && i >= jq && i <= K;
+              acc[k][q] = ok[k][q] ? src[i] : 0.0;
+            }
+          }
           const int ra = min(i0 - J, nr - 1), rb = min(i0 + 64 - J, nr - 1);  // clamped panel rows (masked on store)
           const int cj = j0 - J;
-          for (int c = 0; c < jb; ++c) {
+          const int cq[4] = {min(cj, nr - 1), min(cj + 1, nr - 1), min(cj + 2, nr - 1), min(cj + 3, nr - 1)};
+          int c = 0;
+          for (; c + 4 <= jb; c += 4) {  // 24 LDS reads in flight, then 32 fma
+            double pa[4], pb[4], pj[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double* col = pan + (c + u) * ldp;
+              pa[u] = col[ra];
+              pb[u] = col[rb];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pj[u][q] = col[cq[q]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                acc[0][q] = fma(-pa[u], pj[u][q], acc[0][q]);
+                acc[1][q] = fma(-pb[u], pj[u][q], acc[1][q]);
+              }
+          }
+          for (; c < jb; ++c) {
             const double* col = pan + c * ldp;
             const double pa = col[ra], pb = col[rb];
-            double pj[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pj[q] = col[min(cj + q, nr - 1)];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              acc[0][q] = fma(pa, pj[q], acc[0][q]);
-              acc[1][q] = fma(pb, pj[q], acc[1][q]);
+              const double pj = col[cq[q]];
+              acc[0][q] = fma(-pa, pj, acc[0][q]);
+              acc[1][q] = fma(-pb, pj, acc[1][q]);
             }
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int jq = j0 + q;
-            if (jq < K) {
-              double* dst = L + (int64_t)jq * ldl;
+            double* dst = L + (int64_t)min(j0 + q, K - 1) * ldl;
 #pragma unroll
-              for (int k = 0; k < 2; ++k) {
-                const int i = i0 + 64 * k;
-                if (i >= jq && i <= K) dst[i] -= acc[k][q];
-              }
-            }
+            for (int k = 0; k < 2; ++k)
+              if (ok[k][q]) dst[i0 + 64 * k] = acc[k][q];
           }
         }
         __threadfence_block();
         __syncthreads();
+        PH_QO_MARK(13)
       }
     }
     PH_QO_MARK(4)
@@ -1697,8 +1735,8 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
   __syncthreads();
 #ifdef PH_QO_TIMERS
   if (w < 12 && tid == 0)
-    printf("qo timers (100 MHz ticks) sweep %lld gram %lld rhs %lld mirror %lld chol %lld backsub %lld recon %lld  K=%d nb=%d\n",
-           tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], boff[nb], nb);
+    printf("qo timers (100 MHz ticks) sweep %lld gram %lld rhs %lld mirror %lld chol(rest) %lld backsub %lld recon %lld | copy %lld panel-load %lld diag %lld rowsolve %lld store %lld trailing %lld  K=%d nb=%d\n",
+           tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[8], tq[9], tq[10], tq[11], tq[12], tq[13], boff[nb], nb);
 #endif
   // outputs.  When the loop stopped on the test function the reference reports all periods
   // but the last one, yet keeps the weights / dictionary of all of them (QOPeriods.py:584-592).
