@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4 single-GPU leg")
     ap.add_argument("--c4-windows", type=int, default=C4_WINDOWS, help="rehearsals only; the reported config is 65536")
-    ap.add_argument("--pieces", type=int, default=4, help="N>1: pieces the scatter of each rank's block is cut into")
+    ap.add_argument("--pieces", type=int, default=8, help="N>1: pieces the scatter of each rank's block is cut into")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
