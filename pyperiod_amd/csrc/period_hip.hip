@@ -1316,7 +1316,7 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(upload_table(c, T_AUX0, phi.data(), phi.size(), &d_phi));
   PH_TRY(upload_table(c, T_AUX1, off.data(), off.size(), &d_off));
   PH_TRY(upload_table(c, T_AUX2, dq.data(), dq.size(), &d_dq));
-  const size_t ws_per = 2 * (size_t)kcap * kcap + 3 * (size_t)kcap;
+  const size_t ws_per = 2 * (size_t)kcap * kcap + 4 * (size_t)kcap;
   PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * ws_per * sizeof(double)));
   Stage st(c, flags);
   const void* dx;

@@ -1346,10 +1346,11 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const T* data = x + w * (int64_t)N;
-  double* G = ws_all + w * (2 * (int64_t)kcap * kcap + 3 * (int64_t)kcap);  // Gram, column-major, ld = kcap
+  double* G = ws_all + w * (2 * (int64_t)kcap * kcap + 4 * (int64_t)kcap);  // Gram, column-major, ld = kcap
   double* L = G + (int64_t)kcap * kcap;                                      // Cholesky factor, ld = kcap + 1
   double* rhs = L + (int64_t)(kcap + 1) * kcap;
   double* wts = rhs + kcap;  // last good weights
+  double* ysv = wts + kcap;  // y = L^-1 rhs of the rows factored so far (kept across the greedy steps)
 
   load_window(data, work, N);
   zero_pad(work, N);
@@ -1500,36 +1501,40 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
     __syncthreads();
     PH_QO_MARK(3)
     // ---- G = L L^T, L y = rhs, L^T w = y.  Right-looking blocked Cholesky of the augmented matrix
-    //      [G; rhs^T] (the rhs is carried as row K of every column, it leaves the factorisation as y):
-    //      the lower triangle is copied into the factor workspace and reduced in place, a block of <= NB
-    //      columns at a time.  The block's columns (all rows below the diagonal) sit in LDS: one wavefront
-    //      factors the diagonal block, every thread then solves one row against it in registers, and the
-    //      trailing matrix is updated in a single sweep -- every element read and written once per block,
-    //      4 columns x 2 rows per lane, coalesced -- so the work per step is K^2 / 2 independent elements
-    //      instead of one narrow panel.
+    //      [G; rhs^T] (the rhs is carried as row K of every column, it leaves the factorisation as y),
+    //      a block of <= NB columns at a time.  The block's columns (all rows below the diagonal) sit in
+    //      LDS: one wavefront factors the diagonal block, every thread then solves one row against it in
+    //      registers, and the trailing matrix is updated in a single sweep -- every element read and
+    //      written once per block, 4 columns x 2 rows per lane, coalesced.
+    //      Bordered: the factor of the rows found in earlier greedy steps (and their y) is kept; only the
+    //      rows of the new dictionary block are copied in and reduced -- the old block columns skip the
+    //      diagonal factorisation and touch the new rows only (-25 % of the work of refactoring from scratch).
     bool singular = false;
     {
       const int ldl = kcap + 1;  // factor workspace: column-major, rows 0..K-1 then the rhs row
       const int ldp = (K + 1) | 1;
       const int nbmax = min(kQoNb, pan_cap / ldp);
-      for (int e = tid; e < K * (K + 1); e += blockDim.x) {
-        const int c = e / (K + 1), r = e - c * (K + 1);
-        if (r >= c) L[(int64_t)c * ldl + r] = r < K ? G[(int64_t)c * kcap + r] : rhs[c];
+      // new rows (and the rhs slot, row K) of every column; the rhs slot of an old column holds its final y
+      for (int e = tid; e < K * (keep + 1); e += blockDim.x) {
+        const int c = e / (keep + 1), r = row0 + (e - c * (keep + 1));
+        if (r >= c) L[(int64_t)c * ldl + r] = r < K ? G[(int64_t)c * kcap + r] : (c < row0 ? ysv[c] : rhs[c]);
       }
       if (tid == 0) *sing_flag = 0;
       __threadfence_block();
       __syncthreads();
       PH_QO_MARK(8)
-      for (int J = 0; J < K; J += nbmax) {
-        const int jb = min(nbmax, K - J);
+      for (int J = 0, jb = 0; J < K; J += jb) {
+        const bool old = J < row0;  // block column of an earlier greedy step: already final above row0
+        jb = old ? min(nbmax, row0 - J) : min(nbmax, K - J);
         const int nr = K - J + 1;  // rows J .. K-1 and the rhs row
+        const int rnew = old ? row0 - J : 0;  // first panel row this step still has to produce
         for (int e = tid; e < nr * jb; e += blockDim.x) {
           const int cc = e / nr, rr = e - cc * nr;
           pan[cc * ldp + rr] = rr >= cc ? L[(int64_t)(J + cc) * ldl + J + rr] : 0.0;
         }
         __syncthreads();
         PH_QO_MARK(9)
-        if (wv == 0) {  // diagonal block jb x jb (jb <= 32), one wavefront, lane = row, left-looking:
+        if (wv == 0 && !old) {  // diagonal block jb x jb (jb <= 32), one wavefront, lane = row, left-looking:
           // column cc of row r is a dot product over the finished columns -- reads only, no
           // read-modify-write chains through LDS
           for (int cc = 0; cc < jb; ++cc) {
@@ -1568,7 +1573,7 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
         }
         // rows below the block (and the rhs row): x D^T = a, forward substitution, 16 columns at a time in
         // registers; the finished half is folded into the columns of the second half before it is dropped
-        for (int rr = jb + tid; rr < nr; rr += blockDim.x) {
+        for (int rr = max(jb, rnew) + tid; rr < (old ? nr - 1 : nr); rr += blockDim.x) {
 #pragma unroll 1
           for (int c_lo = 0; c_lo < jb; c_lo += 16) {
             double xr[16];
@@ -1600,24 +1605,27 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
         for (int e = tid; e < nr * jb; e += blockDim.x) {
           const int cc = e / nr, rr = e - cc * nr;
           if (rr >= cc) {
-            if (rr < nr - 1)
-              L[(int64_t)(J + cc) * ldl + J + rr] = pan[cc * ldp + rr];
-            else
-              yv[J + cc] = pan[cc * ldp + rr];
+            if (rr < nr - 1) {
+              if (rr >= rnew) L[(int64_t)(J + cc) * ldl + J + rr] = pan[cc * ldp + rr];
+            } else {
+              yv[J + cc] = pan[cc * ldp + rr];  // old columns: their kept y; new ones: just solved
+              if (!old) ysv[J + cc] = pan[cc * ldp + rr];
+            }
           }
         }
         PH_QO_MARK(12)
         // trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for j >= J + jb, j <= i <= K
         const int T0 = J + jb;
-        const int ngroups = (K - T0 + 3) >> 2;  // 4 columns per item
-        const int maxch = (K + 1 - T0 + 127) >> 7;  // 128-row chunks of the longest (first) column group
-        // items: (column group g, chunk h) with rows from the group's first diagonal element; later groups
-        // have fewer chunks, their surplus items fall through
+        const int rlo = old ? row0 : 0;            // old block columns only reach the new rows
+        const int ngroups = (K - T0 + 3) >> 2;     // 4 columns per item
+        const int maxch = (K + 1 - max(T0, rlo) + 127) >> 7;  // 128-row chunks of the longest column group
+        // items: (column group g, chunk h) with rows from the group's first target row (its diagonal element,
+        // or the first new row); later groups have fewer chunks, their surplus items fall through
         for (int item = wv; item < ngroups * maxch; item += nw) {
           const int g = item / maxch, h = item - g * maxch;
-          if (128 * h > K - (T0 + 4 * g)) continue;
+          if (128 * h > K - max(T0 + 4 * g, rlo)) continue;
           const int j0 = T0 + 4 * g;
-          const int i0 = j0 + 128 * h + lane;  // rows i0, i0 + 64
+          const int i0 = max(j0, rlo) + 128 * h + lane;  // rows i0, i0 + 64
           // the old values are requested first: their HBM / L2 latency hides behind the dot products
           double acc[2][4];
           bool ok[2][4];
@@ -1628,7 +1636,8 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const int i = i0 + 64 * k;
-              ok[k][q] = jq < K && i >= jq && i <= K;
+              // the rhs slot (row K) of an old column already holds its final y
+              ok[k][q] = jq < K && i >= jq && i <= K && !(i == K && jq < row0);
               acc[k][q] = ok[k][q] ? src[i] : 0.0;
             }
           }
