@@ -1039,9 +1039,14 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, q_hi, &geom));
-  // integer tables: Euler phi and, for every q, q / r for each prime r | q
-  std::vector<int32_t> phi(q_hi + 1), off(q_hi + 2, 0), dd;
+  // tables: for every q the factors (I - P_d) of its projector (d = q / r for each prime r | q, with r and
+  // 1 / r), the scale (q / phi(q))^2, and the row-split geometry of the coset counts below 64
+  std::vector<int32_t> off(q_hi + 2, 0);
+  std::vector<ph::RamStep> steps;
+  std::vector<double> scale2(q_hi + 1, 0.0);
+  std::vector<ph::RamSmall> small(64, ph::RamSmall{0, 0});
   {
+    std::vector<int32_t> phi(q_hi + 1);
     for (int i = 0; i <= q_hi; ++i) phi[i] = i;
     std::vector<std::vector<int32_t>> primes_of(q_hi + 1);
     std::vector<char> comp(q_hi + 1, 0);
@@ -1054,11 +1059,16 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
       }
     }
     for (int q = 0; q <= q_hi; ++q) {
-      off[q] = (int32_t)dd.size();
-      for (int r : primes_of[q]) dd.push_back(q / r);
+      off[q] = (int32_t)steps.size();
+      for (int r : primes_of[q]) steps.push_back(ph::RamStep{q / r, r, 1.0 / (double)r});
+      if (q >= 1) {
+        const double sc = (double)q / (double)phi[q];
+        scale2[q] = sc * sc;
+      }
     }
-    off[q_hi + 1] = (int32_t)dd.size();
-    if (dd.empty()) dd.push_back(1);
+    off[q_hi + 1] = (int32_t)steps.size();
+    if (steps.empty()) steps.push_back(ph::RamStep{1, 1, 1.0});
+    for (int d = 1; d < 64; ++d) small[d] = ph::RamSmall{64 / d, (65536 + d - 1) / d};
   }
   // Root plan: roots are the periods of (q_hi/2, q_hi]; every wanted q <= q_hi/2 becomes the child of one
   // of its multiples there (the least loaded one; children cost a strip fold and a filter, O(Q + q)).
@@ -1086,18 +1096,31 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
     for (int i = 0; i < n_root; ++i) {
       const int Q = order[i];
       tab[4 * i + 0] = Q;
-      tab[4 * i + 1] = (int32_t)(tab.size() - (size_t)4 * n_root);
-      for (int q : kids[Q]) tab.push_back(q);
-      tab[4 * i + 2] = (int32_t)(tab.size() - (size_t)4 * n_root);
+      tab[4 * i + 1] = (int32_t)((tab.size() - (size_t)4 * n_root) / 2);
+      for (int q : kids[Q]) {
+        tab.push_back(q);
+        tab.push_back(Q / q);
+      }
+      tab[4 * i + 2] = (int32_t)((tab.size() - (size_t)4 * n_root) / 2);
       tab[4 * i + 3] = Q >= q_lo ? 1 : 0;
     }
   }
   if (tab.empty()) tab.push_back(0);
-  const int *d_off, *d_d, *d_phi, *d_tab;
+  // the small tables travel as raw int32 words through the cached table slots
+  static_assert(sizeof(ph::RamStep) == 16 && sizeof(ph::RamSmall) == 8, "table records are uploaded as int32 words");
+  std::vector<int32_t> aux((steps.size() * sizeof(ph::RamStep) + scale2.size() * sizeof(double) +
+                            small.size() * sizeof(ph::RamSmall)) / sizeof(int32_t));
+  const size_t steps_words = steps.size() * sizeof(ph::RamStep) / 4, scale_words = scale2.size() * 2;
+  std::memcpy(aux.data(), steps.data(), steps_words * 4);
+  std::memcpy(aux.data() + steps_words, scale2.data(), scale_words * 4);
+  std::memcpy(aux.data() + steps_words + scale_words, small.data(), small.size() * sizeof(ph::RamSmall));
+  const int *d_off, *d_aux, *d_tab;
   PH_TRY(upload_table(c, T_AUX0, off.data(), off.size(), &d_off));
-  PH_TRY(upload_table(c, T_AUX1, dd.data(), dd.size(), &d_d));
-  PH_TRY(upload_table(c, T_AUX3, phi.data(), phi.size(), &d_phi));
+  PH_TRY(upload_table(c, T_AUX1, aux.data(), aux.size(), &d_aux));
   PH_TRY(upload_table(c, T_AUX2, tab.data(), tab.size(), &d_tab));
+  const ph::RamStep* d_steps = reinterpret_cast<const ph::RamStep*>(d_aux);
+  const double* d_scale2 = reinterpret_cast<const double*>(d_aux + steps_words);
+  const ph::RamSmall* d_small = reinterpret_cast<const ph::RamSmall*>(d_aux + steps_words + scale_words);
   Stage st(c, flags);
   const void* dx;
   void* dout;
@@ -1108,14 +1131,14 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   if (n_root > 0) {
     static_assert(sizeof(ph::RamRoot) == 4 * sizeof(int32_t), "RamRoot is uploaded as four ints");
     const ph::RamRoot* d_roots = reinterpret_cast<const ph::RamRoot*>(d_tab);
-    const int* d_child = d_tab + (size_t)4 * n_root;
+    const int2* d_child = reinterpret_cast<const int2*>(d_tab + (size_t)4 * n_root);
     PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
       using T = decltype(t);
       auto kernel = ph::k_ramanujan<T, decltype(lw)::value>;
       PH_TRY(allow_lds(kernel, lds));
       ProfScope ps_(c, "k_ramanujan");
       hipLaunchKernelGGL(kernel, grid, dim3(nw * 64), lds, c->stream, (const T*)dx, N, q_hi, geom, d_roots, n_root, d_child,
-                         d_off, d_d, d_phi, (T*)gwin, (double*)dout);
+                         d_off, d_steps, d_scale2, d_small, (T*)gwin, (double*)dout);
       return (int)PH_OK;
     }));
     PH_TRY(launch_check("k_ramanujan"));

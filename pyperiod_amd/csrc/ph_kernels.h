@@ -1089,11 +1089,25 @@ __device__ __forceinline__ void ram_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Integer and reciprocal constants of the strip steps come from host tables: the kernel is paced by the
+// dependent strip steps of each wavefront (3-4 waves per SIMD), so every division taken out of those
+// chains counts.
+struct RamStep {  // one factor (I - P_d) of E_q: d = q / r cosets of r elements
+  int d;
+  int r;
+  double inv_r;
+};
+struct RamSmall {  // row-split geometry of a coset count d < 64
+  int G;      // 64 / d row groups
+  int inv16;  // ceil(65536 / d): lane / d == (lane * inv16) >> 16 for lane < 64
+};
+
 // Row-split coset sums of s[0 .. len) modulo d < 64 (d | len): lane = g d + i (g < G = 64 / d) adds
 // s[lane + k G d]; the G partial sums of a coset are combined with a shuffle tree.  Returns the coset
 // total in EVERY lane of the coset's column (lane mod d), 0 in the idle lanes >= G d.
-__device__ __forceinline__ double strip_cosets_small(const double* __restrict__ s, int len, int d, int lane) {
-  const int G = 64 / d, L = G * d;
+__device__ __forceinline__ double strip_cosets_small(const double* __restrict__ s, int len, int d, RamSmall sm,
+                                                     int lane) {
+  const int G = sm.G, L = G * d;
   double part = 0.0;
   if (lane < L)
     for (int idx = lane; idx < len; idx += L) part += s[idx];
@@ -1104,20 +1118,19 @@ __device__ __forceinline__ double strip_cosets_small(const double* __restrict__ 
     const double o = __shfl(part, src & (kWave - 1), kWave);
     part += (src < L) ? o : 0.0;
   }
-  const int g = (lane * ((65536 + d - 1) / d)) >> 16;  // lane / d for lane < 64
+  const int g = (lane * sm.inv16) >> 16;                  // lane / d
   const double tot = __shfl(part, lane - g * d, kWave);  // the column's total sits in its first row group
   return lane < L ? tot : 0.0;
 }
 
-// dst[i] = sum_t src[i + t q], i < q  (q | len): the fold of a folded strip.
-__device__ __forceinline__ void strip_fold(const double* __restrict__ src, int len, int q,
-                                           double* __restrict__ dst, int lane) {
+// dst[i] = sum_t src[i + t q], i < q  (len = k q): the fold of a folded strip.
+__device__ __forceinline__ void strip_fold(const double* __restrict__ src, int len, int q, int k,
+                                           const RamSmall* __restrict__ small, double* __restrict__ dst, int lane) {
   if (q < 64) {
-    const double tot = strip_cosets_small(src, len, q, lane);
+    const double tot = strip_cosets_small(src, len, q, small[q], lane);
     if (lane < q) dst[lane] = tot;
     return;
   }
-  const int k = len / q;
   for (int i = lane; i < q; i += kWave) {
     double a0 = 0.0, a1 = 0.0;
     int t = 0;
@@ -1132,12 +1145,14 @@ __device__ __forceinline__ void strip_fold(const double* __restrict__ src, int l
 
 // One factor (I - P_d) of the projector, in place: every element of s[0 .. q) loses the mean of its
 // coset modulo d (r = q / d elements per coset).  Each lane reads and writes only its own elements.
-__device__ __forceinline__ void strip_remove_coset_means(double* __restrict__ s, int q, int d, int lane) {
-  const int r = q / d;
-  const double inv_r = 1.0 / (double)r;
+__device__ __forceinline__ void strip_remove_coset_means(double* __restrict__ s, int q, RamStep st,
+                                                         const RamSmall* __restrict__ small, int lane) {
+  const int d = st.d, r = st.r;
+  const double inv_r = st.inv_r;
   if (d < 64) {
-    const int L = (64 / d) * d;
-    const double m = strip_cosets_small(s, q, d, lane) * inv_r;
+    const RamSmall sm = small[d];
+    const int L = sm.G * d;
+    const double m = strip_cosets_small(s, q, d, sm, lane) * inv_r;
     if (lane < L)
       for (int idx = lane; idx < q; idx += L) s[idx] -= m;
     return;
@@ -1166,19 +1181,20 @@ __device__ __forceinline__ void strip_remove_coset_means(double* __restrict__ s,
 
 // s holds S_q: apply E_q in place and reduce to norms[q] (all lanes get it).
 __device__ __forceinline__ double ram_emit(double* __restrict__ s, int q, const PGeom* __restrict__ geom,
-                                           const int* __restrict__ pr_off, const int* __restrict__ pr_d,
-                                           const int* __restrict__ totient, int lane) {
+                                           const int* __restrict__ pr_off, const RamStep* __restrict__ steps,
+                                           const double* __restrict__ scale2, const RamSmall* __restrict__ small,
+                                           int lane) {
   for (int k = pr_off[q]; k < pr_off[q + 1]; ++k) {
-    strip_remove_coset_means(s, q, pr_d[k], lane);
+    strip_remove_coset_means(s, q, steps[k], small, lane);
     ram_wave_sync();
   }
-  const int rows = geom[q].rows, nfull = geom[q].nfull;
-  const double scale = (double)q / (double)totient[q];
-  const double s2 = scale * scale;
+  const int nfull = geom[q].nfull;
+  const double cf = (double)geom[q].rows, cs = cf - 1.0;
+  const double s2 = scale2[q];  // (q / phi(q))^2
   double acc = 0.0;
   for (int j = lane; j < q; j += kWave) {
     const double o = s[j] * s2;
-    acc += (double)(j < nfull ? rows : rows - 1) * o * o;
+    acc += (j < nfull ? cf : cs) * o * o;
   }
   return wave_sum(acc);
 }
@@ -1187,10 +1203,11 @@ template <typename T, bool LW>
 __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __restrict__ x, int N, int q_hi,
                                                                 const PGeom* __restrict__ geom,
                                                                 const RamRoot* __restrict__ roots, int n_root,
-                                                                const int* __restrict__ child_q,
+                                                                const int2* __restrict__ child_q,
                                                                 const int* __restrict__ pr_off,
-                                                                const int* __restrict__ pr_d,
-                                                                const int* __restrict__ totient, T* gwin,
+                                                                const RamStep* __restrict__ steps,
+                                                                const double* __restrict__ scale2,
+                                                                const RamSmall* __restrict__ small, T* gwin,
                                                                 double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
@@ -1231,15 +1248,15 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
     ram_wave_sync();
     // ---- children: fold of the strip, filtered in the scratch strip
     for (int c = c0; c < c1; ++c) {
-      const int q = child_q[c];
-      strip_fold(sA, Q, q, sB, lane);
+      const int q = child_q[c].x;  // .y = Q / q
+      strip_fold(sA, Q, q, child_q[c].y, small, sB, lane);
       ram_wave_sync();
-      const double v = ram_emit(sB, q, geom, pr_off, pr_d, totient, lane);
+      const double v = ram_emit(sB, q, geom, pr_off, steps, scale2, small, lane);
       if (lane == 0) orow[q] = v;
       ram_wave_sync();  // sB is rewritten by the next child
     }
     if (roots[i].emit) {
-      const double v = ram_emit(sA, Q, geom, pr_off, pr_d, totient, lane);
+      const double v = ram_emit(sA, Q, geom, pr_off, steps, scale2, small, lane);
       if (lane == 0) orow[Q] = v;
     }
     ram_wave_sync();  // sA is rewritten by the next root
