@@ -43,7 +43,7 @@ def test_header_constants_match_binding():
 
     text = open(os.path.join(ROOT, "include", "periodhip.h")).read()
     for name in ("PH_OK", "PH_E_ARG", "PH_E_HIP", "PH_E_NOMEM", "PH_E_CAP", "PH_E_UNSUPPORTED", "PH_F64", "PH_F32",
-                 "PH_FLAG_TRUNC", "PH_FLAG_ORTH", "PH_FLAG_SINGLE", "PH_FLAG_DEVICE", "PH_SWEEP_NORM",
+                 "PH_FLAG_TRUNC", "PH_FLAG_ORTH", "PH_FLAG_SINGLE", "PH_FLAG_DEVICE", "PH_FLAG_NOSYNC", "PH_SWEEP_NORM",
                  "PH_SWEEP_NORM_GAMMA", "PH_SWEEP_MAXABS", "PH_ST_OK", "PH_ST_NO_PERIOD", "PH_ST_ITER_CAP", "PH_ST_CAP"):
         m = re.search(rf"#define {name} \(?(-?\d+)u?\)?", text)
         assert m, name
@@ -59,6 +59,18 @@ def test_argument_errors_without_gpu(lib):
     assert b"ctx" in lib.ph_last_error()
     with pytest.raises(ValueError):
         _ffi.check(rc)
+
+
+def test_helper_entry_points_reject_null_without_gpu(lib):
+    """The round-2 helpers (pass-plan info, QOPeriods feasibility) validate their arguments on the host."""
+    from pyperiod_amd import _ffi
+
+    n_pass, n_per, ok = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(7)
+    assert lib.ph_sweep_plan_info(None, 2, 1365, ctypes.byref(n_pass), ctypes.byref(n_per)) == _ffi.PH_E_ARG
+    assert lib.ph_qo_feasible(None, _ffi.PH_F64, 4096, -1, 512, ctypes.byref(ok)) == _ffi.PH_E_ARG
+    assert lib.ph_small_to_large(None, None, 0, 1, 16, 0.1, -1, None, None, 0, _ffi.PH_FLAG_DEVICE | _ffi.PH_FLAG_NOSYNC, 4,
+                                 None, None, None, None, None) == _ffi.PH_E_ARG
+    assert _ffi.PH_FLAG_NOSYNC == 16
 
 
 def test_product_has_no_cpu_fallback(lib):

@@ -253,6 +253,14 @@ def test_small_to_large_device_pointer_cap_overflow_is_reported(eng):
                                              _ffi.PH_FLAG_DEVICE, 2, c2.data_ptr(), p2.data_ptr(), w2.data_ptr(), None, s2.data_ptr()))
 
 
+def test_plan_info_and_feasibility_helpers(eng):
+    n_pass, n_per = eng.sweep_plan_info(2, 1365)
+    assert n_per == 1364 and 600 < n_pass < 1364  # multi-period passes: fewer passes than periods
+    assert eng.sweep_plan_info(2, 63) == (62, 62)  # below 64 every period is its own (row-split) pass
+    assert eng.qo_feasible(4096, np.float64, 512) and eng.qo_feasible(40000, np.float64, 512)  # long windows: HBM residual
+    assert not eng.qo_feasible(4096, np.float64, 4096)  # beyond the row capacity of the workspace
+
+
 def test_empty_batch_returns_empty_outputs(eng):
     """W == 0 (a trailing rank's shard, pyperiod_amd/dist.py): no launch, correctly shaped outputs."""
     x = np.zeros((0, 256))
