@@ -100,9 +100,9 @@ const char* ph_profile_name(ph_ctx* ctx, int i);
 /* Multiprocessor count and per-workgroup LDS limit of the context's device. */
 int ph_device_info(ph_ctx* ctx, int* num_cu, int* lds_bytes);
 /* Largest N for which a window of `dtype` stays LDS-resident (the fast path).  Longer windows are
- * accepted by project/sweep/m_best/small_to_large/best_correlation/ramanujan_norms -- the window
- * then lives in an HBM workspace -- and rejected (PH_E_ARG) by best_frequency, qo_find_periods,
- * fold_sums and orth_powers.  `flags` is ignored. */
+ * accepted by every entry point: the window then lives in (or is read straight from) HBM / L2 --
+ * project, sweep, m_best, small_to_large, best_correlation, ramanujan_norms, best_frequency,
+ * qo_find_periods, fold_sums and orth_powers alike.  `flags` is ignored. */
 int ph_max_window(ph_ctx* ctx, int dtype, unsigned flags, int* max_n);
 
 /* Pass plan of the norm sweeps (ph_sweep norm modes, ph_m_best, ph_qo_find_periods) over the
@@ -172,9 +172,10 @@ int ph_best_correlation(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N,
 /* ---- Periods.best_frequency (Periods.py:351-398) ----------------------------------------
  * num times: k = argmax |rfft(residual, win_size)| (first maximum, Periods.py:386-389),
  * p = round(2 win_size / k) (:390-391, round-half-even), project, store, subtract (:392-397).
- * The spectrum is a direct real DFT over the first min(N, win_size) samples (any win_size, no FFT
- * library; bins spread over the whole GPU, so a single window is fast too), twiddles from a
- * float64 table; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH (orth tables must cover
+ * The spectrum is an in-LDS radix-2 FFT when win_size is a power of two whose complex work array
+ * fits the LDS (win_size <= 8192), otherwise a direct real DFT over the first min(N, win_size)
+ * samples (any win_size, no FFT library; bins spread over the whole GPU, so a single window is fast
+ * too); twiddles from a float64 table in both cases; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH (orth tables must cover
  * p <= 2 win_size).  win_size < 1 = N (:381-382).  Two launches per round; W <= 65535.
  * periods (W, num) uint32; powers (W, num) float64 = norm / ||data|| (:397-399); bases
  * (W, num, N).  status PH_ST_NO_PERIOD: the spectral peak was bin 0 (or the spectrum NaN) at
@@ -188,7 +189,9 @@ int ph_best_frequency(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, i
 /* ---- RamanujanPeriods.find_periods (RamanujanPeriods.py:67-86 with :124-169) ------------
  * out (W, q_hi + 1) float64; entries below q_lo are zero (RamanujanPeriods.py:71).
  * Evaluated in float64 through the folded form (fold to S_q, Moebius-filter with the
- * integer Ramanujan sum c_q); the reference accumulates in float32, parity is 1e-5. */
+ * integer Ramanujan sum c_q); the reference accumulates in float32, parity is 1e-5.
+ * Any range: q_hi = N / 3 (the reference default, RamanujanPeriods.py:68-69) works for
+ * N = 4096 .. 16384 and beyond, as long as one wavefront's strips (12 q_hi bytes) fit the LDS. */
 int ph_ramanujan_norms(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int q_lo,
                        int q_hi, unsigned flags, double* out);
 
@@ -201,8 +204,9 @@ int ph_dict_project(ph_ctx* ctx, const double* x, const double* basis, int rows,
 /* ---- QOPeriods.find_periods, non-orthogonal / update_weights=True branch -----------------
  * (QOPeriods.py:373-596, get_subspaces :830-840, solve_quadratic :779-796) with the default
  * test function rms(reconstruction) > rms(data) * thresh.  The whole greedy loop runs on the
- * device, one workgroup per window: gamma sweep, phi-mass row bookkeeping, Gram matrix and
- * right-hand side by folds, Cholesky solve, reconstruction, residual.
+ * device, one workgroup per window: gamma sweep, phi-mass row bookkeeping, Gram matrix (closed-form
+ * counts) and right-hand side by folds, bordered blocked Cholesky solve, reconstruction, residual.
+ * Any N (the residual moves to an HBM workspace when it does not fit the LDS beside the solver).
  * periods/norms/keeps (W, num): dictionary blocks in the order found (period, gamma norm, rows
  * kept); counts (W, 2) = {periods the reference reports, blocks in the dictionary} (they differ
  * by one when the test function stopped the loop, QOPeriods.py:584-592); weights (W, kcap)
