@@ -532,6 +532,18 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   double rn = dn;                       // periodic_norm(residual)
   int count = 0;
 
+#ifdef PH_S2L_TIMERS
+  long long ts[4] = {0, 0, 0, 0};
+  long long ts0 = wall_clock64();
+#define PH_S2L_MARK(k)                      \
+  {                                         \
+    const long long now_ = wall_clock64();  \
+    ts[k] += now_ - ts0;                    \
+    ts0 = now_;                             \
+  }
+#else
+#define PH_S2L_MARK(k)
+#endif
   int p = 2;
   while (p <= n_periods) {
     int cand = p;  // the period that gets the exact evaluation of Periods.py:274-281
@@ -575,6 +587,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         if (lane == 0) *cand_slot = mask ? p + __ffsll((long long)mask) - 1 : -1;
       }
       __syncthreads();  // also: psq is rewritten by the next round
+      PH_S2L_MARK(0)
       cand = *cand_slot;
       if (cand < 0) {
         p = hi + 1;
@@ -601,6 +614,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       }
     }
     tsq = block_sum(tsq, red);
+    PH_S2L_MARK(1)
     const double tn = sqrt(tsq) / sqrtN;
     const double imposed = (rn - tn) / dn;
     if (imposed > thresh) {  // strict, Periods.py:281
@@ -632,8 +646,12 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       rn = tn;
     }
     __syncthreads();
+    PH_S2L_MARK(2)
     p = cand + 1;
   }
+#ifdef PH_S2L_TIMERS
+  if (w < 6 && tid == 0) printf("s2l timers (100 MHz ticks) screen %lld exact %lld update %lld  accepts %d\n", ts[0], ts[1], ts[2], count);
+#endif
   if (tid == 0) {
     counts[w] = count;
     status_out[w] = count > cap ? 3 : 0;
