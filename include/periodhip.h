@@ -173,9 +173,9 @@ int ph_best_correlation(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N,
  * num times: k = argmax |rfft(residual, win_size)| (first maximum, Periods.py:386-389),
  * p = round(2 win_size / k) (:390-391, round-half-even), project, store, subtract (:392-397).
  * The spectrum is an in-LDS radix-2 FFT when win_size is a power of two whose complex work array
- * fits the LDS (win_size <= 8192), otherwise a direct real DFT over the first min(N, win_size)
- * samples (any win_size, no FFT library; bins spread over the whole GPU, so a single window is fast
- * too); twiddles from a float64 table in both cases; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH (orth tables must cover
+ * fits the LDS (win_size <= 8192), Bluestein's chirp convolution on two such FFTs for any other
+ * win_size up to about 5400, otherwise a direct real DFT over the first min(N, win_size) samples
+ * (no FFT library; bins spread over the whole GPU); twiddles from float64 tables in every case; the projection honours PH_FLAG_TRUNC / PH_FLAG_ORTH (orth tables must cover
  * p <= 2 win_size).  win_size < 1 = N (:381-382).  Two launches per round; W <= 65535.
  * periods (W, num) uint32; powers (W, num) float64 = norm / ||data|| (:397-399); bases
  * (W, num, N).  status PH_ST_NO_PERIOD: the spectral peak was bin 0 (or the spectrum NaN) at

@@ -72,6 +72,8 @@ struct ph_ctx {
   int geom_n = -1, geom_max_p = -1;
   DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
   int twid_len = -1;
+  DevBuf bs_tab;  // Bluestein tables of the last (win_size, min(N, win_size)): M twiddles, chirp, FFT of the wrapped chirp
+  int bs_L = -1, bs_M0 = -1;
   DevBuf plan;  // pass plan of the norm sweeps, cached for the last (p_lo, p_hi)
   int plan_lo = -1, plan_hi = -1, plan_n = 0, plan_m = -1;
   int plan_max_m = 4;  // largest row-class count a pass may use (PH_PLAN_MAX_M overrides: 1, 2 or 4)
@@ -520,6 +522,7 @@ int ph_destroy(ph_ctx* c) {
   if (c->geom.p) (void)hipFree(c->geom.p);
   if (c->plan.p) (void)hipFree(c->plan.p);
   if (c->twid.p) (void)hipFree(c->twid.p);
+  if (c->bs_tab.p) (void)hipFree(c->bs_tab.p);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -938,7 +941,75 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
   const bool use_fft = (L & (L - 1)) == 0 && L >= 4 && lds_fft <= (size_t)c->lds_limit && !std::getenv("PH_BF_DIRECT");
   int logL = 0;
   while ((1 << logL) < L) ++logL;
-  const int nchunk = use_fft ? 1 : (L / 2 + 1 + ph::kBfBlock - 1) / ph::kBfBlock;
+  // any other win_size: Bluestein's chirp convolution on two FFTs of size M >= min(N, L) + L / 2 + 1, if that fits
+  const int M0 = std::min(N, L);
+  int logM = 0;
+  while ((1LL << logM) < (long long)M0 + L / 2 + 1) ++logM;
+  const int M = 1 << logM;
+  const size_t lds_chirp = 2 * carve_bytes(M, 8) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4);
+  const bool use_chirp = !use_fft && L >= 4 && logM <= 20 && lds_chirp <= (size_t)c->lds_limit && !std::getenv("PH_BF_DIRECT");
+  const int nchunk = (use_fft || use_chirp) ? 1 : (L / 2 + 1 + ph::kBfBlock - 1) / ph::kBfBlock;
+  const int wlen = std::max(M0, L / 2 + 1);  // chirp entries the kernel and the wrapped filter need
+  if (use_chirp && (c->bs_L != L || c->bs_M0 != M0)) {
+    const long double pi = 3.141592653589793238462643383279L;
+    std::vector<double> tab(2 * ((size_t)M + wlen + M));  // [twiddles M | chirp wlen | B M] as (re, im) pairs
+    double* twm = tab.data();
+    double* chp = twm + 2 * (size_t)M;
+    double* bf = chp + 2 * (size_t)wlen;
+    for (int k = 0; k < M; ++k) {
+      const long double a = 2.0L * pi * (long double)k / (long double)M;
+      twm[2 * (size_t)k] = (double)std::cos(a);
+      twm[2 * (size_t)k + 1] = (double)std::sin(a);
+    }
+    for (int n = 0; n < wlen; ++n) {  // n^2 mod 2L keeps the angle exact and small
+      const long double a = pi * (long double)(((long long)n * n) % (2LL * L)) / (long double)L;
+      chp[2 * (size_t)n] = (double)std::cos(a);
+      chp[2 * (size_t)n + 1] = (double)std::sin(a);
+    }
+    // B = FFT_M of the wrapped conj(w): b[m] = exp(+i pi m^2 / L) for m in [0, L/2] and at M - m for m in [1, M0)
+    std::vector<long double> br((size_t)M, 0.0L), bi((size_t)M, 0.0L);
+    for (int m = 0; m <= L / 2; ++m) {
+      br[m] = chp[2 * (size_t)m];
+      bi[m] = chp[2 * (size_t)m + 1];
+    }
+    for (int m = 1; m < M0; ++m) {
+      br[M - m] = chp[2 * (size_t)m];
+      bi[M - m] = chp[2 * (size_t)m + 1];
+    }
+    for (int i = 1, j = 0; i < M; ++i) {  // bit reversal, then iterative radix-2 (host, long double)
+      int bit = M >> 1;
+      for (; j & bit; bit >>= 1) j ^= bit;
+      j ^= bit;
+      if (i < j) {
+        std::swap(br[i], br[j]);
+        std::swap(bi[i], bi[j]);
+      }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+      const int half = len >> 1;
+      for (int j = 0; j < half; ++j) {
+        const long double a = -2.0L * pi * (long double)j / (long double)len;
+        const long double wr = std::cos(a), wi = std::sin(a);
+        for (int i = j; i < M; i += len) {
+          const long double xr = br[i + half] * wr - bi[i + half] * wi, xi = br[i + half] * wi + bi[i + half] * wr;
+          br[i + half] = br[i] - xr;
+          bi[i + half] = bi[i] - xi;
+          br[i] += xr;
+          bi[i] += xi;
+        }
+      }
+    }
+    for (int k = 0; k < M; ++k) {
+      bf[2 * (size_t)k] = (double)br[k];
+      bf[2 * (size_t)k + 1] = (double)bi[k];
+    }
+    PH_HIP(hipStreamSynchronize(c->stream));
+    PH_TRY(ensure(c, c->bs_tab, tab.size() * sizeof(double)));
+    PH_HIP(hipMemcpyAsync(c->bs_tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PH_HIP(hipStreamSynchronize(c->stream));
+    c->bs_L = L;
+    c->bs_M0 = M0;
+  }
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, flags, orth_off, orth_q, table_max_p, 2 * L, &tb));
   if (c->twid_len != L) {  // twiddles in float64; k / L is an exact fraction of a turn
@@ -980,12 +1051,18 @@ int ph_best_frequency(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int
     constexpr bool LW = decltype(lw)::value;
     PH_TRY(allow_lds(ph::k_bf_spectrum<T, LW>, lds_spec));
     if (use_fft) PH_TRY(allow_lds(ph::k_bf_fft<T>, lds_fft));
+    if (use_chirp) PH_TRY(allow_lds(ph::k_bf_chirp<T>, lds_chirp));
     PH_TRY(allow_lds(ph::k_bf_update<T, LW>, lds));
     for (int it = 0; it < num; ++it) {
       if (use_fft) {
         ProfScope ps_(c, "k_bf_fft");
         hipLaunchKernelGGL((ph::k_bf_fft<T>), grid_u, dim3(kBlockWide), lds_fft, c->stream, (const T*)dres, N, L, logL,
                            (const double2*)c->twid.p, (const int*)dstat, dpart, dpartk);
+      } else if (use_chirp) {
+        const double2* twm = (const double2*)c->bs_tab.p;
+        ProfScope ps_(c, "k_bf_chirp");
+        hipLaunchKernelGGL((ph::k_bf_chirp<T>), grid_u, dim3(kBlockWide), lds_chirp, c->stream, (const T*)dres, N, L, M, logM,
+                           twm, twm + M, twm + M + wlen, (const int*)dstat, dpart, dpartk);
       } else {
         ProfScope ps_(c, "k_bf_spectrum");
         hipLaunchKernelGGL((ph::k_bf_spectrum<T, LW>), grid_s, dim3(ph::kBfBlock), lds_spec, c->stream, (const T*)dres, N, L,

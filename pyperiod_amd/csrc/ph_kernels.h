@@ -911,37 +911,15 @@ __global__ __launch_bounds__(kBfBlock) void k_bf_spectrum(const T* __restrict__ 
   }
 }
 
-// Power-of-two win_size that fits the LDS: the spectrum is an in-LDS radix-2 FFT (decimation in time,
-// bit-reversed load, log2 L stages of L / 2 butterflies, twiddles from the same float64 table), one
-// workgroup per window -- O(L log L) instead of the O(N L) of the direct DFT above.  Leaves the same
-// (|X|^2, bin + 1) record, first maximum, in chunk slot 0.
-template <typename T>
-__global__ __launch_bounds__(kBlockWide) void k_bf_fft(const T* __restrict__ res, int N, int L, int logL,
-                                                       const double2* __restrict__ tw,
-                                                       const int* __restrict__ status,
-                                                       double* __restrict__ part_m2, int* __restrict__ part_k) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Carve cv(smem);
-  double* re = cv.take<double>(L);
-  double* im = cv.take<double>(L);
-  double* wbest = cv.take<double>(kMaxWaves);
-  int* wbestp = cv.take<int>(kMaxWaves);
-  const int64_t w = blockIdx.x;
-  if (status[w] != 0) return;  // the reference has raised for this window already
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
-  const int M = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
-  const T* xs = res + w * (int64_t)N;
-  for (int n = tid; n < L; n += blockDim.x) {
-    const int r = (int)(__brev((unsigned)n) >> (32 - logL));
-    re[r] = n < M ? (double)xs[n] : 0.0;
-    im[r] = 0.0;
-  }
-  __syncthreads();
+// In-LDS radix-2 FFT stages (decimation in time; the data is already in bit-reversed order):
+// log2 L stages of L / 2 butterflies, twiddles exp(-2 pi i j / 2^s) from a float64 (cos, sin) table
+// of the L-th roots.  Ends with a barrier.
+__device__ __forceinline__ void lds_fft_stages(double* __restrict__ re, double* __restrict__ im, int L, int logL,
+                                               const double2* __restrict__ tw) {
   for (int s = 1; s <= logL; ++s) {
     const int half = 1 << (s - 1);
-    const int tstep = L >> s;  // twiddle index step: exp(-2 pi i j / 2^s) = conj(tw[j * L / 2^s])
-    for (int b = tid; b < (L >> 1); b += blockDim.x) {
+    const int tstep = L >> s;
+    for (int b = threadIdx.x; b < (L >> 1); b += blockDim.x) {
       const int j = b & (half - 1);
       const int a0 = ((b >> (s - 1)) << s) + j, a1 = a0 + half;
       const double2 cs = tw[j * tstep];  // (cos, sin) of +angle; the forward transform uses cos - i sin
@@ -955,9 +933,17 @@ __global__ __launch_bounds__(kBlockWide) void k_bf_fft(const T* __restrict__ res
     }
     __syncthreads();
   }
+}
+
+// First maximum of re[k]^2 + im[k]^2 over k <= kmax -> the (|X|^2, bin + 1) record of window w, slot 0.
+__device__ __forceinline__ void bf_store_peak(const double* __restrict__ re, const double* __restrict__ im, int kmax,
+                                              double* wbest, int* wbestp, int64_t w, double* __restrict__ part_m2,
+                                              int* __restrict__ part_k) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   double best = -1.0;
   int bestk = 0;  // bin + 1; 0 = none
-  for (int k = tid; k <= (L >> 1); k += blockDim.x) {
+  for (int k = tid; k <= kmax; k += blockDim.x) {
     const double m2 = re[k] * re[k] + im[k] * im[k];
     if (m2 > best) {  // false for NaN; ascending k per thread keeps the first maximum
       best = m2;
@@ -981,6 +967,96 @@ __global__ __launch_bounds__(kBlockWide) void k_bf_fft(const T* __restrict__ res
     part_m2[w] = best;
     part_k[w] = bestk;
   }
+}
+
+// Power-of-two win_size that fits the LDS: the spectrum is an in-LDS radix-2 FFT, one workgroup per
+// window -- O(L log L) instead of the O(N L) of the direct DFT above.  Leaves the same
+// (|X|^2, bin + 1) record, first maximum, in chunk slot 0.
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_bf_fft(const T* __restrict__ res, int N, int L, int logL,
+                                                       const double2* __restrict__ tw,
+                                                       const int* __restrict__ status,
+                                                       double* __restrict__ part_m2, int* __restrict__ part_k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  double* re = cv.take<double>(L);
+  double* im = cv.take<double>(L);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  const int64_t w = blockIdx.x;
+  if (status[w] != 0) return;  // the reference has raised for this window already
+  const int M0 = N < L ? N : L;  // rfft(data, L) truncates or zero-pads to L samples
+  const T* xs = res + w * (int64_t)N;
+  for (int n = threadIdx.x; n < L; n += blockDim.x) {
+    const int r = (int)(__brev((unsigned)n) >> (32 - logL));
+    re[r] = n < M0 ? (double)xs[n] : 0.0;
+    im[r] = 0.0;
+  }
+  __syncthreads();
+  lds_fft_stages(re, im, L, logL, tw);
+  bf_store_peak(re, im, L >> 1, wbest, wbestp, w, part_m2, part_k);
+}
+
+// Any other win_size whose chirp convolution fits the LDS: Bluestein.  With w[n] = exp(-i pi n^2 / L),
+//   X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]),
+// a convolution evaluated with two radix-2 FFTs of size M >= min(N, L) + L/2 + 1 (only the bins k <= L/2
+// are needed, so M is about 1.5 L instead of 2 L): a = x w (zero-padded) -> FFT -> times B = FFT(conj(w),
+// wrapped; built once per (L, N) on the host) -> inverse FFT.  |X[k]| = |c[k]|, the final chirp is skipped.
+template <typename T>
+__global__ __launch_bounds__(kBlockWide) void k_bf_chirp(const T* __restrict__ res, int N, int L, int M, int logM,
+                                                         const double2* __restrict__ twm,
+                                                         const double2* __restrict__ chirp,
+                                                         const double2* __restrict__ bfft,
+                                                         const int* __restrict__ status,
+                                                         double* __restrict__ part_m2, int* __restrict__ part_k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  double* re = cv.take<double>(M);
+  double* im = cv.take<double>(M);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  const int64_t w = blockIdx.x;
+  if (status[w] != 0) return;
+  const int M0 = N < L ? N : L;
+  const T* xs = res + w * (int64_t)N;
+  for (int n = threadIdx.x; n < M; n += blockDim.x) {
+    const int r = (int)(__brev((unsigned)n) >> (32 - logM));
+    double ar = 0.0, ai = 0.0;
+    if (n < M0) {
+      const double xv = (double)xs[n];
+      const double2 cs = chirp[n];  // (cos, sin)(pi n^2 / L); w[n] = cos - i sin
+      ar = xv * cs.x;
+      ai = -xv * cs.y;
+    }
+    re[r] = ar;
+    im[r] = ai;
+  }
+  __syncthreads();
+  lds_fft_stages(re, im, M, logM, twm);
+  // pointwise product with B, conjugated for the inverse transform (ifft(z) = conj(fft(conj(z))) / M), and
+  // moved to bit-reversed order: element n and its mirror are handled by the thread that owns min(n, brev(n))
+  for (int n = threadIdx.x; n < M; n += blockDim.x) {
+    const int r = (int)(__brev((unsigned)n) >> (32 - logM));
+    if (n > r) continue;
+    const double2 b0 = bfft[n];
+    const double p0r = re[n] * b0.x - im[n] * b0.y, p0i = re[n] * b0.y + im[n] * b0.x;
+    if (r == n) {
+      re[n] = p0r;
+      im[n] = -p0i;
+    } else {
+      const double2 b1 = bfft[r];
+      const double p1r = re[r] * b1.x - im[r] * b1.y, p1i = re[r] * b1.y + im[r] * b1.x;
+      re[r] = p0r;
+      im[r] = -p0i;
+      re[n] = p1r;
+      im[n] = -p1i;
+    }
+  }
+  __syncthreads();
+  lds_fft_stages(re, im, M, logM, twm);
+  // c[k] = conj(result[k]) / M: the magnitudes only differ by the common factor 1 / M (kept out: the record is
+  // only compared with the other bins of the same window)
+  bf_store_peak(re, im, L >> 1, wbest, wbestp, w, part_m2, part_k);
 }
 
 template <typename T, bool LW>

@@ -319,9 +319,10 @@ def test_best_frequency_device_variants(eng):
             rper, rpw, rbs = po.best_frequency(x[w], win, 3)
             assert np.array_equal(per[w], rper), (win, w)
             assert rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL, (win, w)
-    # power-of-two win_size runs the in-LDS FFT, anything else the direct DFT: same peaks
+    # power-of-two win_size runs the in-LDS FFT, other sizes Bluestein's chirp convolution (direct DFT only when
+    # neither fits the LDS): same peaks
     x4 = multi_sinusoid_batch(50, 3, 4096)
-    for win in (None, 8192, 1024):
+    for win in (None, 8192, 1024, 3000, 5000, 4095):  # FFT (powers of two) and Bluestein (the rest)
         per, pw, bs, st = eng.best_frequency(x4, win, 4)
         for w in range(3):
             rper, rpw, rbs = po.best_frequency(x4[w], win, 4)
