@@ -93,6 +93,8 @@ def main():
         del x
     if "bf" in which:
         run("best_frequency_num5_256x4096", lambda: eng.best_frequency(x4k[:256], None, 5), 256, "windows")
+        x2k = torch.from_numpy(multi_sinusoid_batch(0, 256, 2000)).to(dev)  # the README length: not a power of two
+        run("best_frequency_num5_256x2000", lambda: eng.best_frequency(x2k, None, 5), 256, "windows")
     if "orth" in which:
         run("orth_powers_256x4096", lambda: eng.orth_powers(x4k[:256]), 256, "windows")
     if "misc" in which:
