@@ -244,8 +244,9 @@ def best_frequency(data, win_size=None, num=5, trunc=False, orth=False):
 # --------------------------------------------------------------------------------------
 
 
-def m_best(data, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False):
-    """m_best (gamma=False, Periods.py:408-430) / m_best_gamma (gamma=True, :432-454)."""
+def m_best(data, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False, trace=None):
+    """m_best (gamma=False, Periods.py:408-430) / m_best_gamma (gamma=True, :432-454).
+    `trace` (a dict, test tooling only) receives the step-1 picks before step 2 reshuffles them."""
     n = len(data)
     if max_length is None:
         max_length = n // 3  # :485-486
@@ -279,6 +280,9 @@ def m_best(data, num=5, max_length=None, min_length=2, gamma=False, trunc=False,
             i += 1
             repeats = 0
         work = work - top_base  # always, :537
+
+    if trace is not None:
+        trace["step1_periods"], trace["step1_norms"] = periods.copy(), norms.copy()
 
     # ---- step 2 (:540-598).  The `changed` flag is reset at the top of every inner
     # iteration (:544) and the inner loop can only end on an `i += 1` branch, so the outer

@@ -193,6 +193,25 @@ def test_m_best_batch_vs_oracle(eng):
             assert rel_err(pw[w], rpw) < TOL and rel_err(bs[w], rbs) < TOL
 
 
+def test_m_best_exhausted_range_boundary(eng):
+    """DESIGN.md section 3, known limit: max_length = 7 offers six candidate periods; once 6 and 4 are removed
+    the projections onto 2 and 3 are zero up to rounding, so a FIFTH step-1 pick is BLAS-nrm2 rounding noise in
+    the reference (norm ~1e-17) and not reproducible.  Everything up to that pick is: asking for four periods
+    agrees bit for bit (including the step-2 split the noise pick can block or allow when five are asked for)."""
+    n, t = 672, np.arange(672)
+    for seed in (2, 3, 4):
+        rng = np.random.default_rng(seed)
+        x = np.sin(2 * np.pi * t / int(rng.integers(9, 160))) + 0.05 * rng.standard_normal(n)
+        tr = {}
+        po.m_best(x, 5, 7, 2, False, trace=tr)
+        assert tr["step1_norms"].min() < 1e-12 * tr["step1_norms"].max()  # the case is what the docstring says
+        rper, rpw, rbs = po.m_best(x, 4, 7, 2, False, trace=tr)
+        assert tr["step1_norms"].min() > 1e-6 * tr["step1_norms"].max()
+        per, pw, bs, st = eng.m_best(x[None, :], 4, 7, 2, False)
+        assert st[0] == 0 and np.array_equal(per[0], rper), seed
+        assert rel_err(pw[0], rpw) < TOL and rel_err(bs[0], rbs) < TOL, seed
+
+
 def test_m_best_zero_window_reports_status(eng):
     from pyperiod_amd import Periods, _ffi
 
