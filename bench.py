@@ -83,8 +83,9 @@ def _cpu_worker(args):
     return calls[0], dt
 
 
-def cpu_baseline(n, num, per_worker=8):
-    """The oracle on every host core of this box (one window per call, like the reference)."""
+def cpu_baseline(n, num, per_worker=64):
+    """The oracle on the host cores of this box (one window per call, like the reference): 64 windows per core as
+    BASELINE.md plans, about 16 s of CPU work."""
     import multiprocessing as mp
 
     avail = os.cpu_count() or 1

@@ -43,6 +43,14 @@ def _raise_status(status, what):
         raise RuntimeError(f"{what}: iteration bound reached before `num` periods were found")
 
 
+def _empty_result(x, num, batched):
+    """num == 0: the reference's loops do not run and it returns its zero-length arrays
+    (np.zeros(0, uint32), np.zeros(0), np.zeros((0, N)); Periods.py:316-318,376-378,488-490)."""
+    w, n = x.shape
+    per, pw, bs = np.zeros((w, 0), np.uint32), np.zeros((w, 0)), np.zeros((w, 0, n))
+    return (per, pw, bs) if batched else (per[0], pw[0], bs[0])
+
+
 class Periods:
     PRIMES = PRIMES  # Periods.py:121
 
@@ -99,6 +107,8 @@ class Periods:
         x, batched = self._batch(data)
         if max_length is None:
             max_length = math.floor(x.shape[1] / 3)
+        if num == 0:
+            return _empty_result(x, num, batched)
         per, nr, bs, st = default_engine().best_correlation(
             x, num, max_length, ratio, self._trunc_to_integer_multiple, self._orthogonalize
         )
@@ -106,14 +116,17 @@ class Periods:
         return (per, nr, bs) if batched else (per[0], nr[0], bs[0])
 
     def best_frequency(self, data, win_size: int = None, num: int = 5):
-        """Best-frequency (Periods.py:351-398) on the GPU: spectral peak by a direct real DFT,
-        p = round(2 win_size / k), project, subtract -- one call for all `num` rounds."""
+        """Best-frequency (Periods.py:351-398) on the GPU: spectral peak of the rfft of length win_size (in-LDS
+        radix-2 FFT, Bluestein for other lengths, direct DFT beyond the LDS), p = round(2 win_size / k),
+        project, subtract -- one call for all `num` rounds."""
         x, batched = self._batch(data)
         n = x.shape[1]
         if win_size is None:
             win_size = n
         elif win_size < n:
             warn("win_size is smaller than the input signal length. It will be truncated and information will be lost.")
+        if num == 0:
+            return _empty_result(x, num, batched)
         per, pw, bs, st = default_engine().best_frequency(
             x, win_size, num, self._trunc_to_integer_multiple, self._orthogonalize
         )
@@ -137,6 +150,8 @@ class Periods:
         x, batched = self._batch(data)
         if max_length is None:
             max_length = math.floor(x.shape[1] / 3)
+        if num == 0:
+            return _empty_result(x, num, batched)
         per, pw, bs, st = default_engine().m_best(
             x, num, max_length, min_length, type is not None, self._trunc_to_integer_multiple, self._orthogonalize
         )
