@@ -120,7 +120,7 @@ int upload_table(ph_ctx* c, int slot, const int32_t* src, size_t n, const int** 
   t.valid = false;
   // the previous content may still be in use by queued kernels
   PH_HIP(hipStreamSynchronize(c->stream));
-  PH_TRY(ensure(c, t.dev, n * sizeof(int32_t)));
+  PH_TRY(ensure(c, t.dev, n * sizeof(int32_t) + 256));  // 64 readable words behind the table (wave-wide list reads)
   t.host.assign(src, src + n);
   PH_HIP(hipMemcpyAsync(t.dev.p, t.host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   PH_HIP(hipStreamSynchronize(c->stream));
@@ -730,7 +730,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   int max_fac = 1;  // most proper divisors any candidate period has
   for (int q = 0; q <= max_length; ++q) max_fac = std::max(max_fac, fac_off[q + 1] - fac_off[q]);
   size_t lds2 = carve_bytes(N + kPad, sz) + carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) +
-                carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8);
+                carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8) + carve_bytes(max_fac, 4) +
+                carve_bytes(kMaxWaves, sizeof(ph::PGeom)) + 3 * carve_bytes(num, 4) + carve_bytes(std::max(max_fac, 64), 4);
   void *gbuf1, *gbuf2;
   PH_TRY(place_second_buffer(c, &lds1, general, (size_t)N * sz, W, &gbuf1));
   // step 2 materialises a projection only when a row is split (rare) or in the trunc/orth modes:
@@ -767,6 +768,11 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   PH_TRY(st.out(B_OUT4, n_sweeps, (size_t)W * sizeof(int32_t), &dsweeps));
   PH_TRY(ensure(c, c->buf[B_WS0], (size_t)W * sizeof(double)));
   double* dnorm = static_cast<double*>(c->buf[B_WS0].p);
+  // compact basis rows between the two kernels: the first p elements of every row (ph_kernels.h, step 2);
+  // 16-byte aligned rows of a whole number of 128-element LDS-DMA pieces
+  const int row_stride = (max_length + 127) & ~127;
+  PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * num * row_stride * sz));
+  void* drows = c->buf[B_WS1].p;
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const int max_iters = 12 * (P + num) + 64;
   const dim3 grid((unsigned)W);
@@ -784,7 +790,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
                                                                          : c->sweep_block;
     hipLaunchKernelGGL(kernel, grid, dim3(block1), lds1, c->stream, (const T*)dx, N, num, min_length,
                        max_length, gamma, kflags, tb, geom, plan, n_pass, (T*)gbuf1, (T*)gwin1, max_iters,
-                       (uint32_t*)dper, (double*)dpow, (T*)dbases, dnorm, (int*)dstat, (int*)dsweeps);
+                       (uint32_t*)dper, (double*)dpow, (T*)drows, row_stride, dnorm, (int*)dstat, (int*)dsweeps);
     return (int)PH_OK;
   }));
   PH_TRY(launch_check("k_mbest_step1"));
@@ -796,7 +802,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
     hipLaunchKernelGGL(kernel, grid, dim3(general ? kBlock : c->sweep_block), lds2, c->stream, N, num, gamma,
                        max_length, kflags, tb, geom,
                        max_fac, (T*)gbuf2, (T*)gwin2, (uint32_t*)dper, (double*)dpow, (T*)dbases, dnorm,
-                       (const int*)dstat);
+                       (const int*)dstat, (T*)drows, row_stride);
     return (int)PH_OK;
   }));
   PH_TRY(launch_check("k_mbest_step2"));

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
                                                         const PassPlan* __restrict__ plan, int n_pass,
                                                         T* __restrict__ gbuf, T* gwin,
                                                         int max_iters, uint32_t* __restrict__ periods_out,
-                                                        double* __restrict__ norms_out, T* __restrict__ bases_out,
-                                                        double* __restrict__ dnorm_out,
+                                                        double* __restrict__ norms_out, T* __restrict__ rows_out,
+                                                        int row_stride, double* __restrict__ dnorm_out,
                                                         int* __restrict__ status_out,
                                                         int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,7 +207,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   const int lane = tid & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
-  T* bases = bases_out + w * (int64_t)num * N;
+  // Basis rows leave step 1 in COMPACT form: row k of the window is the mean vector of its period (the first
+  // p elements of the tiled projection; the projection is p-periodic in every flag mode), row_stride elements
+  // apart.  Step 2 refines them and writes the (num, N) matrix once, in final order.
+  T* rows = rows_out + w * (int64_t)num * row_stride;
 
   load_window(x + w * (int64_t)N, work, N);
   zero_pad(work, N);
@@ -316,37 +319,35 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       repeats = 0;
     }
     // ---- project the winner, update bases row, subtract from the residual (:531-537)
-    T* brow = bases + (int64_t)(row < 0 ? 0 : row) * N;
+    T* brow = rows + (int64_t)(row < 0 ? 0 : row) * row_stride;
     if (!general) {
       const Fold f(N, bestp);
       for (int j = tid; j < bestp; j += blockDim.x) {
         const T m = residue_mean(work, f, j, false);
         const int cnt = f.count(j);
-        for (int r = 0; r < cnt; ++r) {
-          const int n = r * bestp + j;
-          if (action == 1)
-            brow[n] = m;
-          else if (action == 2)
-            brow[n] += m;
-          work[n] -= m;
-        }
+        if (action == 1)
+          brow[j] = m;
+        else if (action == 2)
+          brow[j] += m;  // every element of the tiled row would get the same sum (Periods.py:519)
+        for (int r = 0; r < cnt; ++r) work[r * bestp + j] -= m;
       }
     } else {
       project_lds(work, buf, N, bestp, flags, tb);
       for (int n = tid; n < N; n += blockDim.x) {
         const T m = buf[n];
-        if (action == 1)
-          brow[n] = m;
-        else if (action == 2)
-          brow[n] += m;
+        if (n < bestp) {
+          if (action == 1)
+            brow[n] = m;
+          else if (action == 2)
+            brow[n] += m;
+        }
         work[n] -= m;
       }
     }
     __syncthreads();
   }
   __syncthreads();
-  // rows the algorithm never filled stay zero, like np.zeros((num, N)) at Periods.py:490
-  for (int64_t n = (int64_t)filled * N + tid; n < (int64_t)num * N; n += blockDim.x) bases[n] = T(0);
+  // rows the algorithm never filled keep period 0: step 2 writes them as zeros (np.zeros((num, N)), Periods.py:490)
   for (int k = tid; k < num; k += blockDim.x) {
     periods_out[w * num + k] = periods[k];
     norms_out[w * num + k] = norms[k];
@@ -358,20 +359,65 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   }
 }
 
+__device__ __forceinline__ void ram_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ======================================================================================
 // m_best step 2  (Periods.py:540-598): factor refinement, including the reference's
 // quirks: stale `p` in gamma mode (:559,572), `nq` = norm of the LAST factor's projection
 // (:569-572), no advance of i after a split (:581-594).  One workgroup per window.
 // norms_io holds raw norms on entry and powers (norms / ||data||, :600) on exit.
+//   Compact rows.  Basis row i is the tiled mean vector m of its period p (step 1 writes nothing else, a
+//   split keeps it so: the factor's projection is f-periodic, f | p), so step 1 hands over only the first
+//   p elements of every row and np.insert (:585-594) becomes a permutation of row slots: a split writes
+//   two compact rows (the projection into the slot of the row that falls off the end, the remainder in
+//   place) and moves no data.  The (num, N) matrix is written exactly once, at the end, in final order.
+//   For a divisor f of p
+//     S_f[j] = sum_{n < N, n = j (mod f)} row[n] = sum_{k < p, k = j (mod f)} cnt_p[k] m[k],
+//   so the factor norms (plain projection, fp64) fold the count-scaled p-vector -- a "window" of length p
+//   whose every residue mod f has p/f rows -- instead of the N-element row.  The count weights 1/cnt_f[j]
+//   are those of the real window: the fold runs on geom[f] with rows := p/f + 1, whose one extra row for
+//   the residues j < nfull_f reads zeros stored behind the vector.
 // ======================================================================================
+// geom[p] computed in registers (same expressions as prepare_geom on the host; IEEE divisions)
+__device__ __forceinline__ PGeom make_geom(int N, int p) {
+  const int rows = (N + p - 1) / p;
+  PGeom g;
+  g.rows = rows;
+  g.nfull = p - (rows * p - N);
+  g.w_full = 1.0 / (double)rows;
+  g.w_short = rows > 1 ? 1.0 / (double)(rows - 1) : 0.0;
+  return g;
+}
+
+constexpr int kStep2Pre = 3;  // a staged row has at most 3 elements per thread (p <= 3 * blockDim)
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+// rowbuf[n] = row[n mod p], n < N: the tiled row of a compact vector
+template <typename T>
+__device__ __forceinline__ void expand_row(const T* __restrict__ src, int p, T* __restrict__ dst, int N) {
+  const int step = blockDim.x % p;
+  int idx = threadIdx.x % p;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    dst[n] = src[idx];
+    idx += step;
+    if (idx >= p) idx -= p;
+  }
+}
+
 template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step2(int N, int num, int gamma, int stale_p, unsigned flags,
                                                         Tables tb, const PGeom* __restrict__ geom, int max_fac,
                                                         T* __restrict__ gbuf, T* gwin,
                                                         uint32_t* __restrict__ periods_io,
-                                                        double* __restrict__ norms_io, T* __restrict__ bases_io,
+                                                        double* __restrict__ norms_io, T* __restrict__ bases_out,
                                                         const double* __restrict__ dnorm,
-                                                        const int* __restrict__ status) {
+                                                        const int* __restrict__ status, T* __restrict__ rows_io,
+                                                        int row_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* rowbuf = window_buf<T, LW>(cv, gwin, N + kPad);
@@ -380,6 +426,12 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   double* norms = cv.take<double>(num);
   uint32_t* periods = cv.take<uint32_t>(num);
   double* fvals = cv.take<double>(max_fac > 0 ? max_fac : 1);
+  int* ffac = cv.take<int>(max_fac > 0 ? max_fac : 1);
+  PGeom* fgeom = cv.take<PGeom>(kMaxWaves);  // per wavefront: geometry of the fold of a periodic row
+  int* fa = cv.take<int>(num);               // divisor list of row k's period: tb.fac_q[fa[k] .. fb[k])
+  int* fb = cv.take<int>(num);
+  int* slot = cv.take<int>(num);             // compact row of logical row k: rows + slot[k] * row_stride
+  int* ffac_next = cv.take<int>(max_fac > 64 ? max_fac : 64);  // divisor list of the staged row
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -387,40 +439,135 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const bool general = flags & (kTrunc | kOrth);
-  T* bases = bases_io + w * (int64_t)num * N;
+  const bool periodic_rows = sizeof(T) == 8 && !general;
+  T* rows = rows_io + w * (int64_t)num * row_stride;
   for (int k = tid; k < num; k += blockDim.x) {
     norms[k] = norms_io[w * num + k];
-    periods[k] = periods_io[w * num + k];
+    const uint32_t per = periods_io[w * num + k];
+    periods[k] = per;
+    fa[k] = tb.fac_off[per];
+    fb[k] = tb.fac_off[per + 1];
+    slot[k] = k;
   }
   zero_pad(rowbuf, N);
   __syncthreads();
 
   const int gdiv = gamma ? stale_p : 0;
   int i = (status[w] == 0) ? 0 : num;  // a window whose step 1 failed is passed through
+  // a row whose period has no proper divisor (a prime) has nothing to test and is not even read
+  auto next_row = [&](int r) {
+    while (r < num && fa[r] == fb[r]) ++r;
+    return r;
+  };
+  // The rows are short and known one row ahead: the next row's elements and divisor list are copied
+  // HBM -> LDS by LDS-DMA (global_load_lds: no registers, the 64-VGPR fold code has none to spare) into the
+  // unused upper part of rowbuf while the current row is folded -- the loop is otherwise a chain of dependent
+  // HBM round trips (row, divisor list, geometry) per row.  The barrier behind the folds drains the DMA
+  // (hipcc waits vmcnt(0) before __syncthreads).
+  const T* stage = nullptr;
+  int stage_row = -1;
+  // The (num, N) matrix is written exactly once, in final order: logical rows below the loop position can
+  // no longer change (a split inserts at i and moves rows >= i only), so they are tiled out as the loop
+  // passes them -- the stores drain while the next rows are folded.  Rows step 1 never filled (period 0)
+  // are zeros (np.zeros((num, N)), Periods.py:490).
+  T* out = bases_out + w * (int64_t)num * N;
+  int done = 0;
+  auto flush_rows = [&](int upto) {
+    for (; done < upto; ++done) {
+      const int pr = (int)periods[done];
+      T* dst = out + (int64_t)done * N;
+      if (pr == 0) {
+        for (int n = tid; n < N; n += blockDim.x) dst[n] = T(0);
+      } else {
+        expand_row(rows + (int64_t)slot[done] * row_stride, pr, dst, N);
+      }
+    }
+  };
+  i = next_row(i);
   while (i < num) {
     const int per = (int)periods[i];
-    const int a = tb.fac_off[per], b = tb.fac_off[per + 1];
-    if (a == b) {  // no proper divisor (a prime): nothing to test, the row is not even read
-      i += 1;
-      continue;
+    const int a = fa[i], b = fb[i];
+    const T* src = rows + (int64_t)slot[i] * row_stride;
+    // v[k] = cnt_p[k] m[k] for k < per, then zeros for the extra row and the tail reads of the last group
+    const int zend = per + (per >> 1) + 256;
+    const bool short_row = periodic_rows && zend <= N + kPad;
+    if (short_row) {
+      const PGeom gp = make_geom(N, per);
+      const double cf = (double)gp.rows, cs = (double)(gp.rows - 1);
+      if (stage_row == i) {  // the staging area may overlap [0, zend): read, barrier, write
+        double t[kStep2Pre];
+#pragma unroll
+        for (int u = 0; u < kStep2Pre; ++u) {
+          const int k = tid + u * blockDim.x;
+          t[u] = k < per ? (double)stage[k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kStep2Pre; ++u) {
+          const int k = tid + u * blockDim.x;
+          if (k < zend) rowbuf[k] = (T)(t[u] * (k < gp.nfull ? cf : cs));
+        }
+        for (int k = tid + kStep2Pre * blockDim.x; k < zend; k += blockDim.x) rowbuf[k] = T(0);
+        if (tid < b - a) ffac[tid] = ffac_next[tid];
+      } else {
+        for (int k = tid; k < zend; k += blockDim.x)
+          rowbuf[k] = (T)(k < per ? (double)src[k] * (k < gp.nfull ? cf : cs) : 0.0);
+        if (tid < b - a) ffac[tid] = tb.fac_q[a + tid];
+      }
+    } else {  // fp32 rows, trunc / orth modes, periods beyond 2N/3: the tiled row itself
+      expand_row(src, per, rowbuf, N);
+      if (!general && tid < b - a) ffac[tid] = tb.fac_q[a + tid];
     }
-    load_window(bases + (int64_t)i * N, rowbuf, N);
     __syncthreads();
+    flush_rows(i);  // before the LDS-DMA below: a wait on these loads would drain it
+    const int inext = next_row(i + 1);
+    stage_row = -1;
+    if (LW && short_row && inext < num) {  // LW == false: rowbuf is an HBM workspace, nothing to stage into
+      const int pn = (int)periods[inext];
+      const int so = (zend + 1) & ~1;          // 16-byte aligned, behind everything the folds of row i read
+      const int npieces = (pn + 127) >> 7;     // 64 lanes x 16 B = 128 doubles per wave instruction
+      if (pn <= kStep2Pre * (int)blockDim.x && pn + (pn >> 1) + 256 <= N + kPad && so + 128 * npieces <= N &&
+          128 * npieces <= row_stride && fb[inext] - fa[inext] <= 64) {
+        const T* srcn = rows + (int64_t)slot[inext] * row_stride;  // 128 * npieces <= row_stride: stays inside the row
+        for (int j = wv; j < npieces; j += nw)
+          __builtin_amdgcn_global_load_lds((global_void_ptr)(srcn + 128 * j + 2 * lane),
+                                           (lds_void_ptr)(rowbuf + so + 128 * j), 16, 0, 0);
+        if (wv == nw - 1)  // reads up to 63 words behind the list: the device table has that slack
+          __builtin_amdgcn_global_load_lds((global_void_ptr)(tb.fac_q + fa[inext] + lane), (lds_void_ptr)ffac_next, 4, 0, 0);
+        stage = rowbuf + so;
+        stage_row = inext;
+      }
+    }
     double top = 0.0, last = 0.0;
     int topf = -1;
     if (!general) {
       // one wavefront per factor: ||P_f row||^2 = sum_j S_f[j]^2 / cnt_f[j]
-      for (int k = a + wv; k < b; k += nw) {
-        const int f = tb.fac_q[k];
-        const double ss = wave_sum(wave_partial<T, false, LW>(rowbuf, N, f, geom[f], lane));
-        if (lane == 0) fvals[k - a] = periodic_norm_from_sq(ss, N, gdiv);
+      for (int k = wv; k < b - a; k += nw) {
+        const int f = ffac[k];
+        // one call site for both row forms (a second inlined copy of the fold costs spills): the geometry sits
+        // in this wavefront's LDS slot.  Compact row: a "window" of length per with per / f rows per residue,
+        // weights by the real counts of f (rows + 1: see the header; the f < 64 path ignores `rows`).
+        if (lane == 0) {
+          PGeom g;
+          if (short_row) {
+            g = make_geom(N, f);
+            g.rows = per / f + 1;
+          } else {
+            g = geom[f];
+          }
+          fgeom[wv] = g;
+        }
+        ram_wave_sync();
+        const double ss = wave_sum(wave_partial<T, false, LW>(rowbuf, short_row ? per : N, f, fgeom[wv], lane));
+        ram_wave_sync();  // the slot is rewritten for this wavefront's next factor
+        if (lane == 0) fvals[k] = periodic_norm_from_sq(ss, N, gdiv);
       }
       __syncthreads();
-      for (int k = a; k < b; ++k) {  // the reference's scan order (Periods.py:549-563)
-        const double v = fvals[k - a];
+      for (int k = 0; k < b - a; ++k) {  // the reference's scan order (Periods.py:549-563)
+        const double v = fvals[k];
         if (v > top) {
           top = v;
-          topf = tb.fac_q[k];
+          topf = ffac[k];
         }
         last = v;
       }
@@ -445,43 +592,57 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         split = (last + top) > (norms[num - 1] + norms[i]) && last > floor_q && top > floor_q;
       }
     }
+    const int s_here = slot[i], s_last = slot[num - 1];
     __syncthreads();
     if (!split) {
-      i += 1;
+      i = inext;
       continue;
     }
-    // materialise the winning factor's projection exactly, then
-    //   rows i+2.. <- rows i+1.. ; row i+1 <- row i - proj ; row i <- proj   (:581-594)
+    // ---- split (:581-594): materialise the winning factor's projection exactly;
+    //   logical rows i+2.. <- rows i+1.. ; row i+1 <- row i - proj ; row i <- proj ; the last row falls off.
+    //   In compact form: proj (topf elements) goes into the slot of the row that falls off, row i - proj
+    //   (per elements) replaces row i in place, and the slots are renumbered -- no row moves.
+    stage_row = -1;
+    if (short_row) {  // the projection wants the tiled row
+      expand_row(src, per, rowbuf, N);
+      __syncthreads();
+    }
     project_lds(rowbuf, buf, N, topf, flags, tb);
-    for (int r = num - 1; r >= i + 2; --r) {
-      T* dst = bases + (int64_t)r * N;
-      const T* src = bases + (int64_t)(r - 1) * N;
-      for (int n = tid; n < N; n += blockDim.x) dst[n] = src[n];
-    }
-    if (i + 1 < num) {
-      T* dst = bases + (int64_t)(i + 1) * N;
-      for (int n = tid; n < N; n += blockDim.x) dst[n] = rowbuf[n] - buf[n];
-    }
     {
-      T* dst = bases + (int64_t)i * N;
-      for (int n = tid; n < N; n += blockDim.x) dst[n] = buf[n];
+      T* dst = rows + (int64_t)s_last * row_stride;  // i == num - 1: the split row itself falls off
+      if (i + 1 < num) {
+        T* rem = rows + (int64_t)s_here * row_stride;
+        for (int k = tid; k < per; k += blockDim.x) rem[k] = rowbuf[k] - buf[k];
+      }
+      for (int k = tid; k < topf; k += blockDim.x) dst[k] = buf[k];
     }
     if (tid == 0) {
       for (int r = num - 1; r >= i + 2; --r) {
         norms[r] = norms[r - 1];
         periods[r] = periods[r - 1];
+        fa[r] = fa[r - 1];
+        fb[r] = fb[r - 1];
+        slot[r] = slot[r - 1];
       }
       if (i + 1 < num) {
         norms[i + 1] = last;  // the old row keeps its period, weakened (:582-584)
         periods[i + 1] = (uint32_t)per;
+        fa[i + 1] = a;
+        fb[i + 1] = b;
+        slot[i + 1] = s_here;
       }
       norms[i] = top;
       periods[i] = (uint32_t)topf;
+      fa[i] = tb.fac_off[topf];
+      fb[i] = tb.fac_off[topf + 1];
+      slot[i] = s_last;
     }
     __threadfence_block();
     __syncthreads();
+    i = next_row(i);  // the new row i is examined next: i is not advanced (:581-594)
   }
   __syncthreads();
+  flush_rows(num);
   const double dn = dnorm[w];
   for (int k = tid; k < num; k += blockDim.x) {
     periods_io[w * num + k] = periods[k];
@@ -1175,12 +1336,6 @@ __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p
     const T v = xs[has ? (rows - 1) * p + j : 0];
     if (j < p) sbuf[j] = s[c] + (has ? (double)v : 0.0);
   }
-}
-
-__device__ __forceinline__ void ram_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Integer and reciprocal constants of the strip steps come from host tables: the kernel is paced by the
