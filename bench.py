@@ -314,7 +314,10 @@ def main():
                 "traffic_recorded": True,
                 "traffic_source": tsrc,
                 "hbm_frac_measured": (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic and sec > 0) else None,
-                "compulsory_hbm_bytes_per_launch": WINDOWS_PER_GPU * N_SAMPLES * 8 * (1 + NUM_PERIODS),
+                # step 1 reads the windows and hands the basis rows to step 2 in compact form (the first p <= N/3
+                # elements of each row); step 2 writes the (num, N) matrix once (its launch: step2_launch_ms)
+                "compulsory_hbm_bytes_per_launch": WINDOWS_PER_GPU * N_SAMPLES * 8 + WINDOWS_PER_GPU * NUM_PERIODS * (N_SAMPLES // 3) * 8,
+                "compulsory_hbm_bytes_step2": WINDOWS_PER_GPU * NUM_PERIODS * (N_SAMPLES // 3 + N_SAMPLES) * 8,
                 "note": "SURVEY 8d's logical figure (N*8 B per window-projection against 8 TB/s) is kept as logical_hbm_ratio; it "
                 "exceeds 1 because the fused sweep serves every pass but the first from LDS.  The binding roof is LDS read "
                 "bandwidth / VALU issue; frac is the LDS utilisation.",
