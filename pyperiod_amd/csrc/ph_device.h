@@ -49,6 +49,14 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// A value that is identical in every lane, moved into scalar registers: long-lived wave-uniform doubles
+// (norms, thresholds) otherwise hold two VGPRs each in kernels that sit at the 64-VGPR cap.
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // Sum over the workgroup; every thread gets the result.  `red` holds >= 2*kMaxWaves doubles.
 // Partials are combined in wave order, so the result is identical in all threads.
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -60,7 +68,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   double t = 0.0;
   for (int i = 0; i < nw; ++i) t += red[i];
   __syncthreads();
-  return t;
+  return uniform_f64(t);
 }
 
 // ---------------------------------------------------------------- geometry of one fold

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   }
   for (int k = tid; k < (P + 31) / 32; k += blockDim.x) skip[k] = 0u;
   __syncthreads();
-  const double data_norm = periodic_norm_from_sq(block_sumsq(work, N, red), N, 0);
+  const double data_norm = uniform_f64(periodic_norm_from_sq(block_sumsq(work, N, red), N, 0));
 
   int filled = 0;   // `i` of Periods.py:494
   int repeats = 0;  // `iters`
@@ -688,9 +688,9 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   zero_pad(work, N);
   __syncthreads();
   double rsq = block_sumsq(work, N, red);
-  const double sqrtN = sqrt((double)N);
-  const double dn = sqrt(rsq) / sqrtN;  // data_norm, Periods.py:269
-  double rn = dn;                       // periodic_norm(residual)
+  const double sqrtN = uniform_f64(sqrt((double)N));
+  const double dn = uniform_f64(sqrt(rsq) / sqrtN);  // data_norm, Periods.py:269
+  double rn = dn;                                    // periodic_norm(residual)
   int count = 0;
 
 #ifdef PH_S2L_TIMERS
@@ -776,8 +776,8 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     }
     tsq = block_sum(tsq, red);
     PH_S2L_MARK(1)
-    const double tn = sqrt(tsq) / sqrtN;
-    const double imposed = (rn - tn) / dn;
+    const double tn = uniform_f64(sqrt(tsq) / sqrtN);
+    const double imposed = uniform_f64((rn - tn) / dn);
     if (imposed > thresh) {  // strict, Periods.py:281
       T* brow = (bases_out && count < cap) ? bases_out + (w * cap + count) * (int64_t)N : nullptr;
       if (!general) {
