@@ -40,7 +40,7 @@ while time.time() < t_end:
                 s = slice(1, None) if lo == 1 else slice(None)
                 if rel(got[i][s], want[s]) > TOL: bad += 1; print("SWEEP", n, lo, hi, mode, rel(got[i][s], want[s]))
         elif which == 1 and n >= 12:
-            num = int(rng.integers(1, 8)); gamma = bool(rng.integers(0, 2)); ml = int(rng.integers(3, max(4, n//2)))
+            num = int(rng.integers(1, 8)); gamma = bool(rng.integers(0, 2)); ml = int(rng.integers(3, max(4, n//2 if rng.integers(0, 4) else min(n - 1, 700))))
             per, pw, bs, st = eng.m_best(x, num, ml, 2, gamma)
             for i in range(w):
                 tr = {}
