@@ -374,7 +374,8 @@ __device__ __forceinline__ void ram_wave_sync() {
 //   split keeps it so: the factor's projection is f-periodic, f | p), so step 1 hands over only the first
 //   p elements of every row and np.insert (:585-594) becomes a permutation of row slots: a split writes
 //   two compact rows (the projection into the slot of the row that falls off the end, the remainder in
-//   place) and moves no data.  The (num, N) matrix is written exactly once, at the end, in final order.
+//   place) and moves no data.  The (num, N) matrix is written exactly once, in final order, each row as
+//   soon as the loop has passed it.
 //   For a divisor f of p
 //     S_f[j] = sum_{n < N, n = j (mod f)} row[n] = sum_{k < p, k = j (mod f)} cnt_p[k] m[k],
 //   so the factor norms (plain projection, fp64) fold the count-scaled p-vector -- a "window" of length p
@@ -519,7 +520,6 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       if (!general && tid < b - a) ffac[tid] = tb.fac_q[a + tid];
     }
     __syncthreads();
-    flush_rows(i);  // before the LDS-DMA below: a wait on these loads would drain it
     const int inext = next_row(i + 1);
     stage_row = -1;
     if (LW && short_row && inext < num) {  // LW == false: rowbuf is an HBM workspace, nothing to stage into
@@ -562,7 +562,11 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         ram_wave_sync();  // the slot is rewritten for this wavefront's next factor
         if (lane == 0) fvals[k] = periodic_norm_from_sq(ss, N, gdiv);
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA of the next row has landed
       __syncthreads();
+      // rows below i are final: their stores drain behind the scan below and the next row's folds (issued
+      // here, after the wait above, so that the DMA is not held up behind them)
+      flush_rows(i);
       for (int k = 0; k < b - a; ++k) {  // the reference's scan order (Periods.py:549-563)
         const double v = fvals[k];
         if (v > top) {
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         last = v;
       }
     } else {
+      flush_rows(i);
       for (int k = a; k < b; ++k) {
         const int f = tb.fac_q[k];
         const double v = block_sweep_value(rowbuf, buf, N, f, gdiv, flags, tb, red);
