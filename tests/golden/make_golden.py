@@ -7,7 +7,7 @@ reference never travels to the GPU box, the .npz files written here do.
 
 Sections (default: all): kat project sweep small_to_large m_best best_correlation ramanujan
 qoperiods orth_powers m_best_split ramanujan_c3 ramanujan_default ramanujan_weights
-qoperiods_c5.
+qoperiods_c5 m_best_large_p.
 
 Shims -- none of them changes reference arithmetic:
   1. ``builtins.Any = typing.Any`` so that ``import pyPeriod`` survives QOPeriods.py:86.
@@ -363,6 +363,23 @@ def main():
             out[f"fp_{tag}_dict_vals"] = np.array([int(v) for v in res_out["basis_dictionary"].values()])
             out[f"fp_{tag}_residual"] = res.astype(np.float32)  # compared at 1e-4 (fp32 config)
         np.savez_compressed(os.path.join(HERE, "qoperiods_c5.npz"), **out)
+
+    # ---------------------------------------------------------------- m_best with max_length far above N/3
+    if want("m_best_large_p"):
+        # periods beyond N/2 (single-sample residues) and beyond 2N/3; the first case splits 454 -> 227 in step 2.
+        # The inputs are stored: they are not one of the synth generators.
+        out = {}
+        cases = [(600, 500, 4, 0), (257, 210, 3, 1), (1024, 900, 5, 2)]
+        for n, ml, num, seed in cases:
+            rng = np.random.default_rng(seed)
+            x = rng.standard_normal(n) + 2.0 * np.sin(2 * np.pi * np.arange(n) / (0.8 * n))
+            out[f"x_n{n}"] = x
+            for name in ("m_best", "m_best_gamma"):
+                per, pw, bs = getattr(Periods(), name)(x, num=num, max_length=ml)
+                tag = f"{name}_n{n}_ml{ml}_num{num}"
+                out[tag + "_periods"], out[tag + "_powers"], out[tag + "_bases"] = per, pw, bs
+        out["cases"] = np.array(cases, dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, "m_best_large_p.npz"), **out)
 
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print(f"golden fixtures written to {HERE}: {total / 1e6:.2f} MB")

@@ -212,19 +212,20 @@ def test_m_best_exhausted_range_boundary(eng):
         assert rel_err(pw[0], rpw) < TOL and rel_err(bs[0], rbs) < TOL, seed
 
 
-def test_m_best_periods_beyond_two_thirds_of_the_window(eng):
-    """max_length well above the default N/3: rows whose period exceeds 2N/3 take step 2's tiled-row path
-    (the compact p-vector plus its zero row no longer fits the row buffer; the first case really splits
-    454 -> 227 there), periods above N/2 have single-sample residues.  (max_length = N - 1 itself is not a
-    usable case: once p = N - 1 is removed the residual is two samples and every later period ties exactly.)"""
-    for n, ml, num, seed in ((600, 500, 4, 0), (257, 210, 3, 1), (1024, 900, 5, 2)):
-        rng = np.random.default_rng(seed)
-        x = rng.standard_normal(n) + 2.0 * np.sin(2 * np.pi * np.arange(n) / (0.8 * n))
-        for gamma in (False, True):
-            rper, rpw, rbs = po.m_best(x, num, ml, 2, gamma)
-            per, pw, bs, st = eng.m_best(x[None, :], num, ml, 2, gamma)
-            assert st[0] == 0 and np.array_equal(per[0], rper), (n, ml, gamma, per[0], rper)
-            assert rel_err(pw[0], rpw) < TOL and rel_err(bs[0], rbs) < TOL, (n, ml, gamma)
+def test_m_best_periods_beyond_two_thirds_of_the_window(eng, golden):
+    """max_length well above the default N/3 (reference fixture `m_best_large_p`): rows whose period exceeds
+    2N/3 take step 2's tiled-row path (the compact p-vector plus its zero row no longer fits the row buffer;
+    the first case really splits 454 -> 227 there), periods above N/2 have single-sample residues.
+    (max_length = N - 1 itself is not a usable case: once p = N - 1 is removed the residual is two samples and
+    every later period ties exactly.)"""
+    g = golden("m_best_large_p")
+    for n, ml, num, _ in g["cases"]:
+        x = g[f"x_n{n}"]
+        for name, gamma in (("m_best", False), ("m_best_gamma", True)):
+            tag = f"{name}_n{n}_ml{ml}_num{num}"
+            per, pw, bs, st = eng.m_best(x[None, :], int(num), int(ml), 2, gamma)
+            assert st[0] == 0 and np.array_equal(per[0], g[tag + "_periods"]), (tag, per[0])
+            assert rel_err(pw[0], g[tag + "_powers"]) < TOL and rel_err(bs[0], g[tag + "_bases"]) < TOL, tag
 
 
 def test_m_best_zero_window_reports_status(eng):

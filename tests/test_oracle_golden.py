@@ -252,6 +252,18 @@ def test_m_best_step2_splits(golden, name, gamma):
         assert rel_err(bs, g[tag + "_bases"]) < TOL
 
 
+@pytest.mark.parametrize("name,gamma", [("m_best", False), ("m_best_gamma", True)])
+def test_m_best_periods_far_above_a_third_of_the_window(golden, name, gamma):
+    """max_length up to 0.88 N: periods beyond N/2 (single-sample residues) and 2N/3; the first case splits
+    454 -> 227 in step 2 (Periods.py:581-594)."""
+    g = golden("m_best_large_p")
+    for n, ml, num, _ in g["cases"]:
+        tag = f"{name}_n{n}_ml{ml}_num{num}"
+        per, pw, bs = po.m_best(g[f"x_n{n}"], int(num), int(ml), 2, gamma)
+        assert np.array_equal(per, g[tag + "_periods"]), tag
+        assert rel_err(pw, g[tag + "_powers"]) < TOL and rel_err(bs, g[tag + "_bases"]) < TOL, tag
+
+
 def test_ramanujan_config3_shape(golden):
     """N = 8192, q = 2..512 (BASELINE config 3): the fp64 folded form against the float32 reference."""
     g = golden("ramanujan_c3")
