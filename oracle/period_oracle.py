@@ -259,13 +259,18 @@ def m_best(data, num=5, max_length=None, min_length=2, gamma=False, trunc=False,
     # ---- step 1 (:494-537)
     i = 0
     repeats = 0
+    gaps = []
     while i < num:
         top_norm, top_p, top_base = 0, 0, None
+        second = 0.0
         for p in range(min_length, max_length + 1):
             base = project(work, p, trunc, orth)
             nrm = periodic_norm(base, p if gamma else None)
+            if p not in skip:
+                second = max(second, min(nrm, top_norm)) if nrm == nrm else second
             if nrm > top_norm and p not in skip:  # strict: lowest p wins ties, :512
                 top_p, top_norm, top_base = p, nrm, base
+        gaps.append((top_norm - second) / top_norm if top_norm > 0 else 0.0)  # test tooling (trace) only
         present = top_p in set(periods)
         if present and repeats < 10:  # :518-524
             idx = np.where(periods == top_p)[0]
@@ -283,6 +288,7 @@ def m_best(data, num=5, max_length=None, min_length=2, gamma=False, trunc=False,
 
     if trace is not None:
         trace["step1_periods"], trace["step1_norms"] = periods.copy(), norms.copy()
+        trace["step1_min_gap"] = min(gaps) if gaps else 1.0  # smallest relative lead of a winner over the runner-up
 
     # ---- step 2 (:540-598).  The `changed` flag is reset at the top of every inner
     # iteration (:544) and the inner loop can only end on an `i += 1` branch, so the outer

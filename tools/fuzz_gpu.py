@@ -50,8 +50,8 @@ while time.time() < t_end:
                     if st[i] == 0: bad += 1; print("MBEST status", n, num, ml, gamma)
                     continue
                 s1 = np.abs(tr["step1_norms"])
-                if min(np.min(np.abs(r[1])), np.min(s1) / po.periodic_norm(x[i])) < 1e-10 * np.max(np.abs(r[1])):
-                    noise += 1
+                if min(np.min(np.abs(r[1])), np.min(s1) / po.periodic_norm(x[i])) < 1e-10 * np.max(np.abs(r[1])) or tr["step1_min_gap"] < 1e-12:
+                    noise += 1  # ... or two periods tied to the last bits at some pick (the reference's winner is BLAS rounding)
                     continue  # a step-1 pick came from rounding noise of an exhausted residual;
                               # a step-2 split can shift that pick out of the final list, so look at step 1 itself
                 if st[i] != 0 or not np.array_equal(per[i], r[0]) or rel(pw[i], r[1]) > TOL or rel(bs[i], r[2]) > TOL:
