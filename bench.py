@@ -177,8 +177,8 @@ def c4_workload(world, total=C4_WINDOWS):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)  # ~0.9 s timed at N=1: long enough for a 1 Hz utilisation sampler
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4 single-GPU leg")
     ap.add_argument("--c4-windows", type=int, default=C4_WINDOWS, help="rehearsals only; the reported config is 65536")
