@@ -37,17 +37,55 @@ struct Tables {
 };
 
 // ---------------------------------------------------------------- wavefront / block reductions
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+// Cross-lane moves for doubles on gfx950 without ds_bpermute (which costs LDS cycles and a per-lane address
+// register per step -- registers the 64-VGPR kernels spill): DPP moves data inside a row of 16 lanes,
+// v_permlane16_swap / v_permlane32_swap exchange odd-even rows / half-waves of two registers, ds_swizzle's
+// bit mode covers the one remaining distance (lane ^ 4).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i inside each group of 8
+constexpr int kDppRor8 = 0x128;        // row_ror 8: lane i <- lane i ^ 8 inside a row of 16
+
+// v[l ^ 4] (ds_swizzle bit mode: and 0x1f, or 0, xor 4)
+__device__ __forceinline__ double swizzle_xor4_f64(double v) {
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);
+  return __hiloint2double(hi, lo);
+}
+
+// All-reduce over the wavefront with the pairing of the classic xor butterfly (32, 16, 8, 4, 2, 1): every step adds
+// v[l] and v[l ^ o], so the result is bit-identical to a __shfl_xor loop.
+template <bool MAXOP>
+__device__ __forceinline__ double wave_allreduce(double v) {
+  auto op = [](double x, double y) { return MAXOP ? fmax(x, y) : x + y; };
+  {  // l ^ 32: swapping the upper half of one copy with the lower half of the other leaves [lower, lower] / [upper, upper]
+    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    v = op(__hiloint2double((int)r1[0], (int)r0[0]), __hiloint2double((int)r1[1], (int)r0[1]));
+  }
+  {  // l ^ 16: odd rows of one copy against even rows of the other
+    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    v = op(__hiloint2double((int)r1[0], (int)r0[0]), __hiloint2double((int)r1[1], (int)r0[1]));
+  }
+  v = op(v, dpp_f64<kDppRor8>(v));
+  v = op(v, swizzle_xor4_f64(v));
+  v = op(v, dpp_f64<kDppXor2>(v));
+  v = op(v, dpp_f64<kDppXor1>(v));
   return v;
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_allreduce<false>(v); }
+
+__device__ __forceinline__ double wave_max(double v) { return wave_allreduce<true>(v); }
 
 // A value that is identical in every lane, moved into scalar registers: long-lived wave-uniform doubles
 // (norms, thresholds) otherwise hold two VGPRs each in kernels that sit at the 64-VGPR cap.
@@ -325,16 +363,6 @@ __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, 
 // Cross-lane moves for doubles on gfx950 without the LDS crossbar (ds_bpermute):
 // v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows of two registers,
 // DPP moves data inside a row of 16 lanes.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i inside each group of 8
-constexpr int kDppRor8 = 0x128;        // row_ror 8: lane i <- lane i ^ 8 inside a row of 16
 
 // One butterfly level: `lo` and `hi` are per-lane partials of two different periods (or period
 // groups).  Afterwards the lanes whose bit `mask` is clear hold lo summed over the lane pair
