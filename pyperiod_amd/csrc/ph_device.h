@@ -738,15 +738,36 @@ __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N,
 // Wavefront argmax of (value, period): largest value, lowest period among equals
 // (the reference scans p upward with a strict '>', Periods.py:512).  period 0 = none.
 __device__ __forceinline__ void wave_argmax(double& v, int& p) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = __shfl_xor(v, o, kWave);
-    const int op = __shfl_xor(p, o, kWave);
+  // same pairing as wave_allreduce (l ^ 32, 16, 8, 4, 2, 1), without ds_bpermute; the order "larger value, then
+  // lower period, period 0 = none" is total, so both lanes of a pair keep the same winner
+  auto take = [](double& v, int& p, double ov, int op) {
     if (op != 0 && (p == 0 || ov > v || (ov == v && op < p))) {
       v = ov;
       p = op;
     }
+  };
+  {
+    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), a2 = (unsigned)p, b0 = a0, b1 = a1, b2 = a2;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(a2, b2, false, false);
+    v = __hiloint2double((int)r1[0], (int)r0[0]);
+    p = (int)r2[0];
+    take(v, p, __hiloint2double((int)r1[1], (int)r0[1]), (int)r2[1]);
   }
+  {
+    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), a2 = (unsigned)p, b0 = a0, b1 = a1, b2 = a2;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    const auto r2 = __builtin_amdgcn_permlane16_swap(a2, b2, false, false);
+    v = __hiloint2double((int)r1[0], (int)r0[0]);
+    p = (int)r2[0];
+    take(v, p, __hiloint2double((int)r1[1], (int)r0[1]), (int)r2[1]);
+  }
+  take(v, p, dpp_f64<kDppRor8>(v), __builtin_amdgcn_update_dpp(0, p, kDppRor8, 0xF, 0xF, false));
+  take(v, p, swizzle_xor4_f64(v), __builtin_amdgcn_ds_swizzle(p, 0x101F));
+  take(v, p, dpp_f64<kDppXor2>(v), __builtin_amdgcn_update_dpp(0, p, kDppXor2, 0xF, 0xF, false));
+  take(v, p, dpp_f64<kDppXor1>(v), __builtin_amdgcn_update_dpp(0, p, kDppXor1, 0xF, 0xF, false));
 }
 
 // Workgroup-cooperative value of one sweep entry for any flag combination (slow path):
