@@ -69,7 +69,9 @@ struct ph_ctx {
   TableSlot tab[T_COUNT];
   // per-period fold geometry for the tuned sweeps, cached for the last (N, max_p)
   DevBuf geom;
+  DevBuf geomf;  // the same table in float (ph::PGeomF), for the window-pair screen
   int geom_n = -1, geom_max_p = -1;
+  bool step1_pair = true;  // PH_STEP1_PAIR=0: always the one-window fp64 kernel for m_best step 1
   DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
   int twid_len = -1;
   DevBuf bs_tab;  // Bluestein tables of the last (win_size, min(N, win_size)): M twiddles, chirp, FFT of the wrapped chirp
@@ -219,6 +221,11 @@ int prepare_geom(ph_ctx* c, int N, int max_p, const ph::PGeom** out) {
   PH_HIP(hipStreamSynchronize(c->stream));
   PH_TRY(ensure(c, c->geom, host.size() * sizeof(ph::PGeom)));
   PH_HIP(hipMemcpyAsync(c->geom.p, host.data(), host.size() * sizeof(ph::PGeom), hipMemcpyHostToDevice, c->stream));
+  std::vector<ph::PGeomF> hostf(host.size());
+  for (size_t p = 0; p < host.size(); ++p)
+    hostf[p] = ph::PGeomF{host[p].rows, host[p].nfull, (float)host[p].w_full, (float)host[p].w_short};
+  PH_TRY(ensure(c, c->geomf, hostf.size() * sizeof(ph::PGeomF)));
+  PH_HIP(hipMemcpyAsync(c->geomf.p, hostf.data(), hostf.size() * sizeof(ph::PGeomF), hipMemcpyHostToDevice, c->stream));
   PH_HIP(hipStreamSynchronize(c->stream));
   c->geom_n = N;
   c->geom_max_p = max_p;
@@ -493,6 +500,7 @@ int ph_create(int device, ph_ctx** out) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2 || v == 4) c->plan_max_m = v;
   }
+  if (const char* e = std::getenv("PH_STEP1_PAIR")) c->step1_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_STEP1_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
@@ -520,6 +528,7 @@ int ph_destroy(ph_ctx* c) {
   for (TableSlot& t : c->tab)
     if (t.dev.p) (void)hipFree(t.dev.p);
   if (c->geom.p) (void)hipFree(c->geom.p);
+  if (c->geomf.p) (void)hipFree(c->geomf.p);
   if (c->plan.p) (void)hipFree(c->plan.p);
   if (c->twid.p) (void)hipFree(c->twid.p);
   if (c->bs_tab.p) (void)hipFree(c->bs_tab.p);
@@ -776,6 +785,25 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const int max_iters = 12 * (P + num) + 64;
   const dim3 grid((unsigned)W);
+  // Window-pair screen (k_mbest_step1_pair): fp64 windows, plain projection, candidate periods below N, and room for
+  // the pair window plus one fp64 staging buffer in LDS.
+  const size_t lds_pair = 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+                          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * num, 8) + carve_bytes(2 * num, 4) +
+                          carve_bytes(2 * ((P + 31) / 32), 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(16, 4) +
+                          carve_bytes(4, 8);
+  const bool pair = c->step1_pair && dtype == PH_F64 && !general && !gwin1 && !gwin2 && max_length < N &&
+                    lds_pair <= (size_t)c->lds_limit;
+  if (pair) {
+    const size_t gstride = ph::win_stride((size_t)N);
+    PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));
+    auto kernel = ph::k_mbest_step1_pair;
+    PH_TRY(allow_lds(kernel, lds_pair));
+    ProfScope ps_(c, "k_mbest_step1");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((W + 1) / 2)), dim3(1024), lds_pair, c->stream, (const double*)dx, (int)W, N,
+                       num, min_length, max_length, gamma, geom, static_cast<const ph::PGeomF*>(c->geomf.p), plan, n_pass,
+                       static_cast<double*>(c->buf[B_GWIN].p), max_iters, (uint32_t*)dper, (double*)dpow, (double*)drows,
+                       row_stride, dnorm, (int*)dstat, (int*)dsweeps);
+  } else
   PH_TRY(dispatch(dtype, !gwin1, [&](auto t, auto lw) {
     using T = decltype(t);
     auto kernel = ph::k_mbest_step1<T, decltype(lw)::value>;

@@ -109,6 +109,19 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return uniform_f64(t);
 }
 
+// Maximum over the workgroup (every thread gets it; NaN inputs are ignored by fmax, -inf if there is none).
+__device__ __forceinline__ double block_max(double v, double* red) {
+  const int tid = threadIdx.x;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  v = wave_max(v);
+  if ((tid & (kWave - 1)) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmax(t, red[i]);
+  __syncthreads();
+  return uniform_f64(t);
+}
+
 // ---------------------------------------------------------------- geometry of one fold
 struct Fold {
   int p;      // period

@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "ph_device.h"
+#include "ph_pair.h"
 
 namespace ph {
 
@@ -356,6 +357,394 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     dnorm_out[w] = data_norm;
     status_out[w] = status;
     if (sweeps_out) sweeps_out[w] = status == 2 ? iters - 1 : iters;  // all-p sweeps performed
+  }
+}
+
+// ======================================================================================
+// m_best step 1, window-pair screen (plain projection, fp64 windows that fit the LDS twice).
+//   One workgroup owns TWO windows.  LDS holds the pair window pw (element n = {fl32(a[n] sa), fl32(b[n] sb)},
+//   ph_pair.h) and ONE fp64 staging buffer; the fp64 residuals live in an HBM workspace (gres; the input itself
+//   before the first subtraction).  An iteration of Periods.py:496-537 is
+//     1. screen: the pass plan over pw -- every ds_read_b64 / v_pk_add_f32 / address instruction serves both
+//        windows; the 1364 x 2 float values land in the (idle) staging buffer;
+//     2. per window: best lower bound L = max_q (v_q - rad_q), survivors { q : v_q + rad_q >= L } (pair_radius is a
+//        rigorous bound on |screen - exact|, so the exact argmax -- and every period that ties with it in the
+//        rounded norm -- is among them; ~1 survivor per sweep);
+//     3. per window: residual -> staging, survivors re-evaluated in fp64 and compared exactly as k_mbest_step1
+//        does (lazy rounded norms, lowest period among equals), bookkeeping, row-order projection of the winner,
+//        and ONE fused pass that subtracts, sums the squares of the new residual, writes it back to the
+//        workspace and writes its float image into pw.
+//   A window that is not finite / all zero, or whose survivor list overflows, takes every period through the
+//   exact evaluation instead (same decisions as k_mbest_step1, slower).
+// ======================================================================================
+constexpr int kPairListCap = 96;
+constexpr int kPairCoop = 6;  // up to this many survivors are evaluated by the whole workgroup, one after the other
+
+__device__ __forceinline__ bool pair_usable(double rsq) { return rsq > 0.0 && rsq < 1.79e308; }
+
+// power of two that brings the RMS of a window into [0.7, 1.5)
+__device__ __forceinline__ double pair_pick_scale(double rsq, int N) {
+  if (!pair_usable(rsq)) return 1.0;
+  int e;
+  (void)frexp(rsq / (double)N, &e);
+  return ldexp(1.0, -(e >> 1));
+}
+
+// upper bound of ceil(N / q) without an integer division (the radius only has to be an upper bound)
+__device__ __forceinline__ int pair_rows_upper(float fn, int q) {
+  return (int)(fn * __builtin_amdgcn_rcpf((float)q) * 1.000001f) + 1;
+}
+
+// sum_j S_p[j]^2 / cnt_p[j] of the fp64 window `xs` (LDS), residues j = first, first + stride, ... (p >= 64 path)
+__device__ __forceinline__ double pair_exact_part(const double* __restrict__ xs, int p, const PGeom& g, int first, int stride) {
+  double part = 0.0;
+  for (int j = first; j < p; j += stride) {
+    const bool full = j < g.nfull;
+    const double s = column_sum(xs, j, p, full ? g.rows : g.rows - 1);
+    part = fma(s * s, full ? g.w_full : g.w_short, part);
+  }
+  return part;
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_mbest_step1_pair(
+    const double* __restrict__ x, int W, int N, int num, int p_lo, int p_hi, int gamma,
+    const PGeom* __restrict__ geom, const PGeomF* __restrict__ geomf, const PassPlan* __restrict__ plan, int n_pass,
+    double* __restrict__ gres, int max_iters, uint32_t* __restrict__ periods_out, double* __restrict__ norms_out,
+    double* __restrict__ rows_out, int row_stride, double* __restrict__ dnorm_out, int* __restrict__ status_out,
+    int* __restrict__ sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  f2* pw = cv.take<f2>(N + kPad);
+  double* stg = cv.take<double>(N + kPad);
+  double* red = cv.take<double>(kRedDoubles);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  double* norms = cv.take<double>(2 * num);
+  uint32_t* periods = cv.take<uint32_t>(2 * num);
+  const int P = p_hi - p_lo + 1;
+  const int SK = (P + 31) / 32;
+  uint32_t* skip = cv.take<uint32_t>(2 * SK);
+  int* list = cv.take<int>(2 * kPairListCap);
+  // per window w: ctl[w] survivors listed, [2+w] filled (`i` of Periods.py:494), [4+w] repeats (`iters`),
+  // [6+w] status, [8+w] sweeps done, [10+w] still running, [12+w] every period exactly
+  int* ctl = cv.take<int>(16);
+  double* dst2 = cv.take<double>(4);  // [w] sum of squares of the scaled residual (unit of the radius), [2+w] its scale
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const size_t gstride = win_stride((size_t)N);
+  float* pwf = reinterpret_cast<float*>(pw);
+
+  for (int k = tid; k < 2 * num; k += blockDim.x) {
+    norms[k] = 0.0;
+    periods[k] = 0u;
+  }
+  for (int k = tid; k < 2 * SK; k += blockDim.x) skip[k] = 0u;
+  if (tid < 16) ctl[tid] = 0;
+  zero_pad(stg, N);
+  for (int i = tid; i < kPad; i += blockDim.x) pw[N + i] = f2_zero();
+  for (int w = 0; w < 2; ++w) {
+    const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+    const bool exists = gw < W;
+    __syncthreads();
+    if (exists) {
+      load_window(x + gw * (int64_t)N, stg, N);
+    } else {
+      for (int n = tid; n < N; n += blockDim.x) stg[n] = 0.0;
+    }
+    __syncthreads();
+    const double rsq = block_sumsq(stg, N, red);
+    const double sc = uniform_f64(pair_pick_scale(rsq, N));
+    for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] = (float)(stg[n] * sc);
+    if (tid == 0) {
+      dst2[w] = rsq * sc * sc * (1.0 + 1e-9);
+      dst2[2 + w] = sc;
+      ctl[10 + w] = exists ? 1 : 0;
+      ctl[12 + w] = pair_usable(rsq) ? 0 : 1;
+      if (exists) dnorm_out[gw] = periodic_norm_from_sq(rsq, N, 0);
+    }
+  }
+#ifdef PH_PAIR_TIMERS
+  long long ts[5] = {0, 0, 0, 0, 0};
+  long long ts0 = wall_clock64();
+  int nsurv_tot = 0, nall = 0;
+#define PH_PAIR_MARK(k)                     \
+  {                                         \
+    const long long now_ = wall_clock64();  \
+    ts[k] += now_ - ts0;                    \
+    ts0 = now_;                             \
+  }
+#else
+#define PH_PAIR_MARK(k)
+#endif
+  const float fn = (float)N;
+  for (;;) {
+    __syncthreads();
+    const bool act0 = ctl[10] != 0, act1 = ctl[11] != 0;
+    if (!act0 && !act1) break;
+    if (tid == 0) ctl[0] = ctl[1] = 0;  // (read as `ncand` before the last barrier of the previous round)
+    // ---- 1. screen of both windows (Periods.py:501-515 in float); values into the idle staging buffer
+    f2* vals = reinterpret_cast<f2*>(stg);
+    pair_sweep_plan(pw, N, geomf, plan, wv, n_pass, nw, lane, [&](f2 ss, int q) {
+      if ((lane & 7) == 0) vals[q - p_lo] = ss;
+    });
+    __syncthreads();
+    PH_PAIR_MARK(0)
+    // ---- 2. survivors of both windows: two passes over the values (a thread sees the same <= 2 entries twice)
+    {
+      const bool scr0 = act0 && !ctl[12], scr1 = act1 && !ctl[13];
+      if (scr0 || scr1) {
+        const double unit0 = dst2[0], unit1 = dst2[1];
+        double lo0 = -1.0 / 0.0, lo1 = -1.0 / 0.0;
+        for (int idx = tid; idx < P; idx += blockDim.x) {
+          const int q = p_lo + idx;
+          const f2 v = vals[idx];
+          const double rad = pair_radius(pair_rows_upper(fn, q), q);
+          const uint32_t bit = 1u << (idx & 31);
+          double a = (double)v.x - rad * unit0, b = (double)v.y - rad * unit1;
+          if (gamma) {
+            const double rq = 1.0 / (double)q;
+            a *= rq;
+            b *= rq;
+          }
+          if (!(skip[idx >> 5] & bit) && a > lo0) lo0 = a;
+          if (!(skip[SK + (idx >> 5)] & bit) && b > lo1) lo1 = b;
+        }
+        lo0 = wave_max(lo0);
+        lo1 = wave_max(lo1);
+        if (lane == 0) {
+          red[wv] = lo0;
+          red[kMaxWaves + wv] = lo1;
+        }
+        __syncthreads();
+        lo0 = red[0];
+        lo1 = red[kMaxWaves];
+        for (int i = 1; i < nw; ++i) {
+          lo0 = fmax(lo0, red[i]);
+          lo1 = fmax(lo1, red[kMaxWaves + i]);
+        }
+        // periods that tie with the winner in the ROUNDED norm survive too
+        const double thr0 = lo0 - fabs(lo0) * 1e-9, thr1 = lo1 - fabs(lo1) * 1e-9;
+        for (int idx = tid; idx < P; idx += blockDim.x) {
+          const int q = p_lo + idx;
+          const f2 v = vals[idx];
+          const double rad = pair_radius(pair_rows_upper(fn, q), q);
+          const uint32_t bit = 1u << (idx & 31);
+          double a = (double)v.x + rad * unit0, b = (double)v.y + rad * unit1;
+          if (gamma) {
+            const double rq = 1.0 / (double)q;
+            a *= rq;
+            b *= rq;
+          }
+          if (scr0 && !(skip[idx >> 5] & bit) && a >= thr0) {
+            const int k = atomicAdd(&ctl[0], 1);
+            if (k < kPairListCap) list[k] = q;
+          }
+          if (scr1 && !(skip[SK + (idx >> 5)] & bit) && b >= thr1) {
+            const int k = atomicAdd(&ctl[1], 1);
+            if (k < kPairListCap) list[kPairListCap + k] = q;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    PH_PAIR_MARK(1)
+    // ---- 3. exact phase, one window at a time through the staging buffer
+    for (int w = 0; w < 2; ++w) {
+      if (!(w ? act1 : act0)) continue;
+      const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+      int filled = ctl[2 + w], repeats = ctl[4 + w], status = 0, iters = ctl[8 + w];
+      const bool exact_all = ctl[12 + w] != 0 || ctl[w] > kPairListCap;
+      const int ncand = exact_all ? P : ctl[w];
+      double* nrm = norms + w * num;
+      uint32_t* per = periods + w * num;
+      uint32_t* sk = skip + w * SK;
+      const int* lst = list + w * kPairListCap;
+      __syncthreads();
+      if (iters + 1 > max_iters) {
+        status = 2;
+      } else {
+        const double* src = iters == 0 ? x + gw * (int64_t)N : gres + gw * gstride;
+        iters += 1;
+        load_window(src, stg, N);
+        __syncthreads();
+        PH_PAIR_MARK(2)
+#ifdef PH_PAIR_TIMERS
+        nsurv_tot += ncand;
+        nall += exact_all ? 1 : 0;
+#endif
+        double best_ss = 0.0;
+        int bestp = 0;
+        // same comparison as k_mbest_step1: rounded norms only when two candidates nearly tie
+        auto consider = [&](double ss, int p) {
+          if (!(ss > 0.0)) return;
+          bool take = bestp == 0;
+          if (!take) {
+            const double lhs = gamma ? ss * (double)bestp : ss;
+            const double rhs = gamma ? best_ss * (double)p : best_ss;
+            if (lhs > rhs * (1.0 + 1e-14)) {
+              take = true;
+            } else if (lhs >= rhs * (1.0 - 1e-14)) {
+              const double vn = periodic_norm_from_sq(ss, N, gamma ? p : 0);
+              const double vb = periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0);
+              take = vn > vb || (vn == vb && p < bestp);
+            }
+          }
+          if (take) {
+            best_ss = ss;
+            bestp = p;
+          }
+        };
+        double best = 0.0;
+        if (ncand <= kPairCoop) {
+          // few survivors (the normal case): the whole workgroup folds one candidate at a time, a wavefront per
+          // 64 residues; partial sums are combined in wave order, so every thread holds the same value
+          for (int k = 0; k < ncand; ++k) {
+            const int p = exact_all ? p_lo + k : lst[k];
+            if ((sk[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u) continue;
+            const PGeom g = geom[p];
+            double part = 0.0;
+            if (p < 64) {
+              if (wv == 0) part = wave_partial_small(stg, N, p, g, lane);
+            } else {
+              part = pair_exact_part(stg, p, g, tid, blockDim.x);
+            }
+            consider(block_sum(part, red), p);
+          }
+          best = bestp != 0 ? periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0) : 0.0;
+          if (!(best > 0.0)) bestp = 0;  // the reference needs p_norm > 0 (Periods.py:497,512)
+        } else {
+          for (int k = wv; k < ncand; k += nw) {
+            const int p = exact_all ? p_lo + k : lst[k];
+            if ((sk[(p - p_lo) >> 5] >> ((p - p_lo) & 31)) & 1u) continue;
+            const PGeom g = geom[p];
+            const double part = p < 64 ? wave_partial_small(stg, N, p, g, lane) : pair_exact_part(stg, p, g, lane, kWave);
+            consider(wave_sum(part), p);
+          }
+          best = bestp != 0 ? periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0) : 0.0;
+          if (!(best > 0.0)) bestp = 0;
+          if (lane == 0) {
+            wbest[wv] = best;
+            wbestp[wv] = bestp;
+          }
+          __syncthreads();
+          best = 0.0;
+          bestp = 0;
+          for (int i = 0; i < nw; ++i) {
+            const double v = wbest[i];
+            const int pp = wbestp[i];
+            if (pp != 0 && (v > best || (v == best && pp < bestp))) {
+              best = v;
+              bestp = pp;
+            }
+          }
+          __syncthreads();
+        }
+        PH_PAIR_MARK(3)
+        if (bestp == 0) {  // reference: max_base is None -> TypeError at Periods.py:520/537
+          status = 1;
+        } else {
+          // bookkeeping (Periods.py:518-535); identical in every thread
+          int row = -1;
+          for (int k = 0; k < num; ++k)
+            if (per[k] == (uint32_t)bestp) row = k;
+          int action;  // 0 = subtract only, 1 = store new row, 2 = accumulate into existing row
+          __syncthreads();
+          if (row >= 0 && repeats < 10) {
+            action = 2;
+            if (tid == 0) nrm[row] += best;
+            repeats += 1;
+          } else if (row >= 0) {
+            action = 0;
+            if (tid == 0) sk[(bestp - p_lo) >> 5] |= 1u << ((bestp - p_lo) & 31);
+            repeats = 0;
+          } else {
+            action = 1;
+            row = filled;
+            if (tid == 0) {
+              per[row] = (uint32_t)bestp;
+              nrm[row] = best;
+            }
+            filled += 1;
+            repeats = 0;
+          }
+          // project the winner (row order), update the compact basis row, subtract (:531-537).  The new residual is
+          // not needed in LDS again: it goes straight to the workspace and, as floats, into pw.  The scale of the
+          // float image only has to keep the RMS near 1; it is renewed when the residual has shrunk by 2^16.
+          double* brow = rows_out + (gw * (int64_t)num + (row < 0 ? 0 : row)) * row_stride;
+          const bool more = filled < num;
+          const double sc = dst2[2 + w];
+          double* dst = gres + gw * gstride;
+          double acc = 0.0;
+          const Fold f(N, bestp);
+          for (int j = tid; j < bestp; j += blockDim.x) {
+            const double m = residue_mean(stg, f, j, false);
+            const int cnt = f.count(j);
+            if (action == 1)
+              brow[j] = m;
+            else if (action == 2)
+              brow[j] += m;
+            if (more) {
+              for (int r = 0; r < cnt; ++r) {
+                const int n = r * bestp + j;
+                const double v = stg[n] - m;
+                dst[n] = v;
+                pwf[2 * n + w] = (float)(v * sc);
+                acc = fma(v, v, acc);
+              }
+            }
+          }
+          if (more) {
+            const double rsq = block_sum(acc, red);
+            const double unit = rsq * sc * sc;
+            const bool ok = pair_usable(rsq);
+            if (ok && unit < 9.0e-13 * (double)N) {  // RMS of the float image below 2^-20: renew the scale
+              const double sc2 = uniform_f64(pair_pick_scale(rsq, N));
+              const float up = (float)(sc2 / sc);  // a power of two: the rescaled image is the image at the new scale
+              __syncthreads();
+              for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] *= up;
+              if (tid == 0) {
+                dst2[w] = rsq * sc2 * sc2 * (1.0 + 1e-9);
+                dst2[2 + w] = sc2;
+              }
+            } else if (tid == 0) {
+              dst2[w] = unit * (1.0 + 1e-9);
+            }
+            if (tid == 0) ctl[12 + w] = ok ? 0 : 1;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        ctl[2 + w] = filled;
+        ctl[4 + w] = repeats;
+        ctl[6 + w] = status;
+        ctl[8 + w] = iters;
+        ctl[10 + w] = (status == 0 && filled < num) ? 1 : 0;
+      }
+      PH_PAIR_MARK(4)
+    }
+  }
+#ifdef PH_PAIR_TIMERS
+  if (blockIdx.x < 6 && tid == 0)
+    printf("pair timers (100 MHz ticks) screen %lld scan %lld load %lld exact %lld update %lld  candidates %d exact_all %d sweeps %d %d\n",
+           ts[0], ts[1], ts[2], ts[3], ts[4], nsurv_tot, nall, ctl[8], ctl[9]);
+#endif
+  __syncthreads();
+  // rows the algorithm never filled keep period 0: step 2 writes them as zeros (np.zeros((num, N)), Periods.py:490)
+  for (int w = 0; w < 2; ++w) {
+    const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+    if (gw >= W) continue;
+    for (int k = tid; k < num; k += blockDim.x) {
+      periods_out[gw * num + k] = periods[w * num + k];
+      norms_out[gw * num + k] = norms[w * num + k];
+    }
+    if (tid == 0) {
+      status_out[gw] = ctl[6 + w];
+      if (sweeps_out) sweeps_out[gw] = ctl[8 + w];
+    }
   }
 }
 

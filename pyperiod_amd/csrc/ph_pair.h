@@ -1,0 +1,375 @@
+// Window-pair screen of the all-p sweep (gfx950 / CDNA4 only).
+//
+// The norm sweeps of ph_device.h are VALU-issue bound: per ds_read_b64 the fold spends one v_add_f64 plus
+// 2-3 instructions of addressing, masking and reduction.  Here TWO windows share a workgroup and every LDS
+// element is the pair {fl32(a[n] * sa), fl32(b[n] * sb)} of their float-rounded (power-of-two scaled) samples:
+// one ds_read_b64 brings a sample of both windows, v_pk_add_f32 / v_pk_fma_f32 fold both, and every address,
+// mask, weight and cross-lane instruction of a pass is shared between them -- the instruction stream of one
+// fp64 pass now serves two windows.  Always 8-byte aligned, no shifted copies, same register footprint as the
+// fp64 fold (a float pair is as wide as a double).
+//
+// The float values only SCREEN the candidates of an m_best iteration (Periods.py:501-515): a rigorous radius
+// (pair_radius) bounds |screen - exact|, and the periods whose upper bound reaches the best lower bound are
+// re-evaluated in fp64 by the kernel (k_mbest_step1_pair in ph_kernels.h), which decides on those values.
+#pragma once
+
+#include "ph_device.h"
+
+namespace ph {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) f2* pair_ptr;
+
+// float geometry of a period for the screen (host table next to PGeom)
+struct PGeomF {
+  int rows;       // R = ceil(N / p)
+  int nfull;      // residues j < nfull own R samples, the others R-1
+  float w_full;   // fl32(1 / R)
+  float w_short;  // fl32(1 / (R-1))  (0 when R == 1)
+};
+
+__device__ __forceinline__ f2 f2_make(float a, float b) {
+  f2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+__device__ __forceinline__ f2 f2_zero() { return f2_make(0.0f, 0.0f); }
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int CTRL>
+__device__ __forceinline__ f2 dpp_f2(f2 v) {
+  const int a = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), CTRL, 0xF, 0xF, false);
+  const int b = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), CTRL, 0xF, 0xF, false);
+  return f2_make(__int_as_float(a), __int_as_float(b));
+}
+
+// One butterfly level on pairs; see butterfly_merge (ph_device.h) -- the two floats of a pair take the place of
+// the two dwords of a double, so the data movement is instruction for instruction the same.
+__device__ __forceinline__ f2 pair_merge(f2 lo, f2 hi, int mask, int lane) {
+  if (mask == 32 || mask == 16) {
+    unsigned l0 = (unsigned)__float_as_int(lo.x), l1 = (unsigned)__float_as_int(lo.y);
+    unsigned h0 = (unsigned)__float_as_int(hi.x), h1 = (unsigned)__float_as_int(hi.y);
+    if (mask == 32) {
+      const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
+      l0 = r0[0]; h0 = r0[1]; l1 = r1[0]; h1 = r1[1];
+    } else {
+      const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
+      l0 = r0[0]; h0 = r0[1]; l1 = r1[0]; h1 = r1[1];
+    }
+    return f2_make(__int_as_float((int)l0), __int_as_float((int)l1)) +
+           f2_make(__int_as_float((int)h0), __int_as_float((int)h1));
+  }
+  const bool up = lane & mask;  // mask == 8
+  const f2 keep = up ? hi : lo;
+  const f2 send = up ? lo : hi;
+  return keep + dpp_f2<kDppRor8>(send);
+}
+
+__device__ __forceinline__ f2 pair_reduce8(f2 v) {
+  v = v + dpp_f2<kDppHalfMirror>(v);
+  v = v + dpp_f2<kDppXor1>(v);
+  v = v + dpp_f2<kDppXor2>(v);
+  return v;
+}
+
+// ---------------------------------------------------------------- few-row single passes (R <= 6)
+template <int NR, int C, bool MASK>
+__device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int lane, f2& part) {
+  f2 v[NR][C];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[r][c] = ptr[r * p + 64 * c];
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    f2 t = v[0][c];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) t += v[r][c];
+    if (MASK) t = (64 * c + lane < nvalid) ? t : f2_zero();
+    part = f2_fma(t, t, part);
+  }
+}
+
+template <int NR>
+__device__ __forceinline__ void pair_rows_segment(pair_ptr base, int p, int len, int lane, f2& part) {
+  constexpr int CG = NR <= 4 ? 4 : 2;
+  const int nchunks = (len + 63) >> 6;
+  const int whole = len >> 6;
+  int c0 = 0;
+  for (; c0 + CG <= whole; c0 += CG) pair_rows_group<NR, CG, false>(base + 64 * c0, p, 64 * CG, lane, part);
+  for (; c0 + 1 < nchunks; c0 += 2) {
+    asm volatile("" ::: "memory");
+    pair_rows_group<NR, 2, true>(base + 64 * c0, p, len - 64 * c0, lane, part);
+  }
+  if (c0 < nchunks) {
+    asm volatile("" ::: "memory");
+    pair_rows_group<NR, 1, true>(base + 64 * c0, p, len - 64 * c0, lane, part);
+  }
+}
+
+// ---------------------------------------------------------------- general segmented group (see seg_group)
+template <int M, int U, int C, bool MASK>
+__device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, int nvalid, int lane,
+                                               const float (&wgt)[7], f2 (&part)[3]) {
+  static_assert(U % M == 0, "a row block must cover whole class cycles");
+  f2 a[M][C];
+#pragma unroll
+  for (int u = 0; u < M; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) a[u][c] = f2_zero();
+  int r = 0;
+  for (; r + U <= nrows; r += U) {
+    f2 v[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u % M][c] += v[u][c];
+    ptr += U * p;
+  }
+  if (U > 1) {
+    const int rem = nrows - r;
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) {
+      if (u < rem) {
+        asm volatile("" ::: "memory");  // keep the wave-uniform branch (see seg_group)
+        f2 v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = ptr[u * p + 64 * c];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[u % M][c] += v[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    if (MASK) {
+#pragma unroll
+      for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : f2_zero();
+    }
+    if (M == 1) {
+      const f2 t = a[0][c];
+      part[0] = f2_fma(t, t, part[0]);
+    } else if (M == 2) {
+      const f2 e = a[0][c], o = a[1 % M][c], t = e + o;
+      part[0] = f2_fma(t, t, part[0]);
+      part[1] = f2_fma(e, e, part[1]);
+      part[2] = f2_fma(o, o, part[2]);
+    } else {
+      const f2 e = a[0][c] + a[2 % M][c], o = a[1 % M][c] + a[3 % M][c], t = e + o;
+      part[0] = f2_fma(t, t * wgt[0], part[0]);
+      part[1] = f2_fma(e, e * wgt[1], part[1]);
+      part[1] = f2_fma(o, o * wgt[2], part[1]);
+#pragma unroll
+      for (int u = 0; u < M; ++u) part[2] = f2_fma(a[u][c], a[u][c] * wgt[3 + u], part[2]);
+    }
+  }
+}
+
+// Per-lane partials of sum_j S_q[j]^2 / cnt_q[j] of BOTH windows for q = p (M >= 1), 2p (M >= 2), 4p (M == 4),
+// base period p >= 64; same segment logic as wave_pass_seg.
+template <int M>
+__device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, const PGeomF* __restrict__ geom,
+                                              int lane, f2 (&total)[3]) {
+  constexpr int U = (M == 1) ? 2 : M;
+  constexpr int CM = (M == 4) ? 2 : 4;
+  const int rows = geom[p].rows, cut = geom[p].nfull;
+  int qn[3];
+  float qf[3], qs[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int q = (t == 0 || (t == 1 && M >= 2) || M == 4) ? (p << t) : p;
+    qn[t] = geom[q].nfull;
+    qf[t] = geom[q].w_full;
+    qs[t] = geom[q].w_short;
+    total[t] = f2_zero();
+  }
+#pragma unroll 1
+  for (int seg = 0; seg < 2; ++seg) {
+    const int start = seg == 0 ? 0 : cut;
+    const int len = seg == 0 ? cut : p - cut;
+    if (len <= 0) continue;
+    const int nrows = seg == 0 ? rows : rows - 1;
+    float wgt[7];
+    wgt[0] = start < qn[0] ? qf[0] : qs[0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wgt[1 + u] = (start + u * p < qn[1]) ? qf[1] : qs[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wgt[3 + u] = (start + u * p < qn[2]) ? qf[2] : qs[2];
+    const pair_ptr base = (pair_ptr)xs + start + lane;
+    const int nchunks = (len + 63) >> 6;
+    int c0 = 0;
+    const int whole = len >> 6;
+    f2 sacc[3] = {f2_zero(), f2_zero(), f2_zero()};
+    f2(&part)[3] = (M <= 2) ? sacc : total;
+    bool done = false;
+    if (M == 1) {
+      done = true;
+      switch (nrows) {
+        case 1: pair_rows_segment<1>(base, p, len, lane, part[0]); break;
+        case 2: pair_rows_segment<2>(base, p, len, lane, part[0]); break;
+        case 3: pair_rows_segment<3>(base, p, len, lane, part[0]); break;
+        case 4: pair_rows_segment<4>(base, p, len, lane, part[0]); break;
+        case 5: pair_rows_segment<5>(base, p, len, lane, part[0]); break;
+        case 6: pair_rows_segment<6>(base, p, len, lane, part[0]); break;
+        default: done = false; break;
+      }
+    }
+    if (done) {
+    } else if (CM == 4) {
+      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
+      switch (nchunks - c0) {
+        case 4: pair_seg_group<M, U, 4, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 3: pair_seg_group<M, U, 3, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 2: pair_seg_group<M, U, 2, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: pair_seg_group<M, U, 1, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        default: break;
+      }
+    } else {
+      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
+      switch (nchunks - c0) {
+        case 2: pair_seg_group<M, U, 2, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: pair_seg_group<M, U, 1, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        default: break;
+      }
+    }
+    if (M == 1) {
+      total[0] = f2_fma(sacc[0], f2_make(wgt[0], wgt[0]), total[0]);
+    } else if (M == 2) {
+      total[0] = f2_fma(sacc[0], f2_make(wgt[0], wgt[0]), total[0]);
+      total[1] = f2_fma(sacc[1], f2_make(wgt[1], wgt[1]), f2_fma(sacc[2], f2_make(wgt[2], wgt[2]), total[1]));
+    }
+  }
+}
+
+// p < 64: row-split path of wave_fold_small / wave_partial_small for pairs.
+__device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int N, int p, const PGeomF& g, int lane) {
+  const int G = 64 / p;
+  const int L = G * p;
+  const int full = N / L;
+  const bool on = lane < L;
+  const f2* ptr = xs + (on ? lane : 0);
+  f2 s0 = f2_zero(), s1 = f2_zero();
+  int r = 0;
+  for (; r + 4 <= full; r += 4) {
+    const f2 a = ptr[0], b = ptr[L], c = ptr[2 * L], d = ptr[3 * L];
+    s0 += a;
+    s1 += b;
+    s0 += c;
+    s1 += d;
+    ptr += 4 * L;
+  }
+  for (; r < full; ++r) {
+    s0 += ptr[0];
+    ptr += L;
+  }
+  const bool tail = on && (full * L + lane < N);
+  const f2 tv = xs[tail ? full * L + lane : 0];
+  f2 tot = s0 + s1 + (tail ? tv : f2_zero());
+  tot = on ? tot : f2_zero();
+  int s = 1;
+  while (s < G) s <<= 1;
+  for (s >>= 1; s >= 1; s >>= 1) {
+    const int src = lane + s * p;
+    const float ox = __shfl(tot.x, src & (kWave - 1), kWave);
+    const float oy = __shfl(tot.y, src & (kWave - 1), kWave);
+    tot += (src < L) ? f2_make(ox, oy) : f2_zero();
+  }
+  const float w = (lane < g.nfull) ? g.w_full : g.w_short;
+  return (lane < p) ? tot * tot * w : f2_zero();
+}
+
+// The online 8-period butterfly (Butterfly8) on pairs.
+struct PairButterfly8 {
+  f2 l1, l2, l3;
+  int k, myp;
+  __device__ __forceinline__ void reset() {
+    k = 0;
+    myp = 0;
+    l1 = l2 = l3 = f2_zero();
+  }
+  template <typename F>
+  __device__ __forceinline__ void push(f2 a, int p, int lane, F&& consume) {
+    if (butterfly8_slot(lane) == k) myp = p;
+    if ((k & 1) == 0) {
+      l1 = a;
+    } else {
+      a = pair_merge(l1, a, 32, lane);
+      if ((k & 2) == 0) {
+        l2 = a;
+      } else {
+        a = pair_merge(l2, a, 16, lane);
+        if ((k & 4) == 0) {
+          l3 = a;
+        } else {
+          const f2 tot = pair_reduce8(pair_merge(l3, a, 8, lane));
+          if (myp != 0) consume(tot, myp);
+          myp = 0;
+        }
+      }
+    }
+    k = (k + 1) & 7;
+  }
+  template <typename F>
+  __device__ __forceinline__ void flush(int lane, F&& consume) {
+    while (k != 0) push(f2_zero(), 0, lane, consume);
+  }
+};
+
+// Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in the 8 lanes that own period q.
+template <typename F>
+__device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N, const PGeomF* __restrict__ geom,
+                                                const PassPlan* __restrict__ plan, int i_first, int i_end, int stride,
+                                                int lane, F&& consume) {
+  PairButterfly8 bf;
+  bf.reset();
+  for (int i = i_first; i < i_end; i += stride) {
+    const int p = plan[i].p, m = plan[i].m;
+    if (m == 0) {
+      bf.push(pair_partial_small(xs, N, p, geom[p], lane), p, lane, consume);
+    } else if (m == 1) {
+      f2 part[3];
+      pair_pass_seg<1>(xs, p, geom, lane, part);
+      bf.push(part[0], p, lane, consume);
+    } else if (m == 2) {
+      f2 part[3];
+      pair_pass_seg<2>(xs, p, geom, lane, part);
+      bf.push(part[0], p, lane, consume);
+      bf.push(part[1], 2 * p, lane, consume);
+    } else {
+      f2 part[3];
+      pair_pass_seg<4>(xs, p, geom, lane, part);
+      bf.push(part[0], p, lane, consume);
+      bf.push(part[1], 2 * p, lane, consume);
+      bf.push(part[2], 4 * p, lane, consume);
+    }
+  }
+  bf.flush(lane, consume);
+}
+
+// Rigorous radius of the screen, in units of the (scaled) sum of squares ssq of the fp64 residual r:
+//   |screen(q) - sum_j S_q[j]^2 / cnt_q[j]| <= pair_radius(q) * ssq.
+// With u = 2^-24, rf = fl32(r s) (s a power of two, |rf - r s| <= u |r s|), n_j <= R terms per residue and
+// A_j = sum |r s| over the coset: any summation order gives |S^_j - S_j| <= (u + gamma_{R-1}) A_j <= R u' A_j, so
+// |S^_j^2 - S_j^2| / cnt_j <= (2 |S_j| + R u' A_j) R u' A_j / cnt_j <= 2 R u' (1 + R u') Q_j by Cauchy-Schwarz
+// (A_j^2 <= cnt_j Q_j, Q_j = sum (r s)^2 over the coset, sum_j Q_j = ssq).  Squaring, weighting with fl32(1/cnt)
+// and the class sums add <= 6 u per term; the positive sum over q/64 chunks, two segments and the butterfly adds
+// gamma_{q/64 + 10}.  First order: (2 R + q/64 + 16) u; the factor 1.5 and the +32 cover the second-order terms
+// (R u <= 2^-13 for R <= 2048), the error of the fp64 value itself (<= (2R + q/64 + 16) 2^-53) and the error of ssq.
+// Underflow: the windows are scaled to RMS ~ 1, so denormal roundings (<= 2^-149 each) are far below the radius.
+__device__ __forceinline__ double pair_radius(int rows, int q) {
+  return 1.5 * (2.0 * (double)rows + (double)(q >> 6) + 32.0) * 5.9604644775390625e-08;
+}
+
+}  // namespace ph
