@@ -111,6 +111,14 @@ int ph_max_window(ph_ctx* ctx, int dtype, unsigned flags, int* max_n);
  * and 4p).  n_pass * N * sizeof(T) is the number of bytes one sweep reads from LDS. */
 int ph_sweep_plan_info(ph_ctx* ctx, int p_lo, int p_hi, int* n_pass, int* n_periods);
 
+/* Measurement helper: which step-1 kernel ph_m_best runs for these arguments.  fp64 windows in plain mode
+ * that fit the LDS twice are screened two windows per workgroup in packed float (windows_per_workgroup = 2,
+ * one 8-byte LDS element carries a sample of both windows, lds_bytes_per_sample = 8 per PAIR) and only the
+ * survivors of the screen are re-evaluated in fp64; otherwise one window per workgroup is folded in its
+ * own precision (1, sizeof(T)).  A fold pass reads N * lds_bytes_per_sample bytes from LDS per workgroup. */
+int ph_m_best_info(ph_ctx* ctx, int dtype, int N, int num, int min_length, int max_length, unsigned flags,
+                   int* windows_per_workgroup, int* lds_bytes_per_sample);
+
 /* ---- Periods.periodic_norm over a batch (Periods.py:221-241) ---------------------------
  * out[w] = ||x[w]||_2 / sqrt(N), additionally / sqrt(p) when p > 0.  Any N. */
 int ph_periodic_norm(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int p,

@@ -446,6 +446,23 @@ int qo_lds_layout(ph_ctx* c, size_t sz, int N, int max_length, int kcap, size_t*
   return PH_OK;
 }
 
+
+// LDS of k_mbest_step1_pair: the pair window, one fp64 staging buffer, bookkeeping of two windows.
+size_t pair_lds_bytes(int N, int num, int P) {
+  return 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+         carve_bytes(kMaxWaves, 4) + carve_bytes(2 * num, 8) + carve_bytes(2 * num, 4) +
+         carve_bytes(2 * ((P + 31) / 32), 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(16, 4) +
+         carve_bytes(4, 8);
+}
+
+// The window-pair screen serves fp64 windows, plain projection, candidate periods below N, when the pair window
+// and the staging buffer fit the LDS; everything else runs k_mbest_step1.
+bool pair_eligible(const ph_ctx* c, int dtype, int N, int num, int min_length, int max_length, unsigned flags) {
+  const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
+  return c->step1_pair && dtype == PH_F64 && !general && max_length < N && min_length <= max_length &&
+         pair_lds_bytes(N, num, max_length - min_length + 1) <= (size_t)c->lds_limit;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -562,6 +579,17 @@ int ph_sweep_plan_info(ph_ctx* c, int p_lo, int p_hi, int* n_pass, int* n_period
   if (p_lo < 1 || p_hi < p_lo) return fail(PH_E_ARG, "need 1 <= p_lo <= p_hi (got %d, %d)", p_lo, p_hi);
   *n_pass = (int)build_plan(p_lo, p_hi, c->plan_max_m).size();
   *n_periods = p_hi - p_lo + 1;
+  return PH_OK;
+}
+
+int ph_m_best_info(ph_ctx* c, int dtype, int N, int num, int min_length, int max_length, unsigned flags,
+                   int* windows_per_workgroup, int* lds_bytes_per_sample) {
+  if (!c || !windows_per_workgroup || !lds_bytes_per_sample) return fail(PH_E_ARG, "NULL argument");
+  if (dtype != PH_F64 && dtype != PH_F32) return fail(PH_E_ARG, "dtype must be PH_F64 or PH_F32");
+  if (max_length < 0) max_length = N / 3;
+  const bool pair = pair_eligible(c, dtype, N, num, min_length, max_length, flags);
+  *windows_per_workgroup = pair ? 2 : 1;
+  *lds_bytes_per_sample = pair ? 8 : (int)elem_size(dtype);
   return PH_OK;
 }
 
@@ -787,12 +815,8 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   const dim3 grid((unsigned)W);
   // Window-pair screen (k_mbest_step1_pair): fp64 windows, plain projection, candidate periods below N, and room for
   // the pair window plus one fp64 staging buffer in LDS.
-  const size_t lds_pair = 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
-                          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * num, 8) + carve_bytes(2 * num, 4) +
-                          carve_bytes(2 * ((P + 31) / 32), 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(16, 4) +
-                          carve_bytes(4, 8);
-  const bool pair = c->step1_pair && dtype == PH_F64 && !general && !gwin1 && !gwin2 && max_length < N &&
-                    lds_pair <= (size_t)c->lds_limit;
+  const size_t lds_pair = pair_lds_bytes(N, num, P);
+  const bool pair = pair_eligible(c, dtype, N, num, min_length, max_length, flags) && !gwin1 && !gwin2;
   if (pair) {
     const size_t gstride = ph::win_stride((size_t)N);
     PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));

@@ -15,6 +15,44 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_DIST_JOB = {}
+
+
+def pytest_sessionstart(session):
+    """The 2-rank sharding job of tests/test_gpu_dist.py runs as a child process tree that must be started BEFORE this
+    process touches the GPU (a process that has initialised HIP must not fork+exec on the GPU boxes): start it
+    here, while GPU tests are selected and a device is visible; the test collects it."""
+    expr = session.config.getoption("-m") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    try:
+        import torch
+
+        if torch.cuda.device_count() < 1:  # does not initialise the GPU
+            return
+    except Exception:  # noqa: BLE001
+        return
+    import subprocess
+    import tempfile
+
+    out = os.path.join(tempfile.mkdtemp(prefix="ph_dist_"), "result.json")
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_job.py"), "--launch", out])
+    _DIST_JOB.update(proc=proc, out=out)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    proc = _DIST_JOB.get("proc")
+    if proc is not None and proc.poll() is None:
+        proc.wait(timeout=900)
+
+
+@pytest.fixture(scope="session")
+def dist_gpu_job():
+    if "proc" not in _DIST_JOB:
+        pytest.skip("no GPU visible at session start")
+    return _DIST_JOB["proc"], _DIST_JOB["out"]
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

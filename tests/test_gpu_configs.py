@@ -489,3 +489,37 @@ def test_batch_interface_edges(eng):
     assert per.shape == (3, 3) and bs.shape == (3, 3, 512)
     res = Periods().small_to_large(xb, thresh=0.05)
     assert len(res) == 3 and res[1][0] == po.small_to_large(xb[1], 0.05)[0]
+
+
+def test_config5_full_batch_fp32(eng, golden):
+    """Config 5 at its per-GPU batch: 1024 fp32 windows of N = 16384 in ONE launch of ph_qo_find_periods
+    (QOPeriods.py:313-596).  Every window finishes (status 0, no dictionary overflow), the batch equals the
+    per-window calls bit for bit, two windows are checked against the fp64 oracle on the rounded input, and the two
+    windows of the reference fixture `qoperiods_c5` sit inside the batch."""
+    import torch
+
+    n, W = 16384, 1024
+    xb = multi_sinusoid_batch(0, W, n, dtype=np.float32)  # windows 0 and 7 are the fixture's
+    xd = torch.from_numpy(xb).cuda()
+    per, nrm, keeps, counts, wts, resid, st = [t.cpu().numpy() for t in eng.qo_find_periods(xd, 3, 0.1, 8, 300, 1024)]
+    assert per.shape == (W, 3) and resid.shape == (W, n) and resid.dtype == np.float32
+    assert int(np.abs(st).max()) == 0
+    assert counts[:, 1].max() <= 3 and int(keeps.sum(axis=1).max()) <= 1024
+    assert np.isfinite(resid).all() and np.isfinite(nrm).all()
+    # the residual never carries more energy than the window
+    assert (np.square(resid.astype(np.float64)).sum(axis=1) <= np.square(xb.astype(np.float64)).sum(axis=1) * (1 + 1e-6)).all()
+    for w in (0, 511, 1023):  # batch == per-window
+        one = eng.qo_find_periods(xb[w : w + 1], 3, 0.1, 8, 300, 1024)
+        assert np.array_equal(one[0][0], per[w]) and np.array_equal(one[2][0], keeps[w]) and np.array_equal(one[3][0], counts[w])
+        assert np.array_equal(one[1][0], nrm[w]) and np.array_equal(one[5][0], resid[w])
+    for w in (3, 700):  # fp64 oracle on the rounded input
+        out, res = po.qo_find_periods(xb[w].astype(np.float64), 3, 0.1, 8, 300)
+        nrep, nb = counts[w]
+        assert np.array_equal(per[w, :nrep], out["periods"]) and list(keeps[w, :nb]) == list(out["basis_dictionary"].values())
+        k = int(keeps[w, :nb].sum())
+        assert rel_err(nrm[w, :nrep], out["norms"]) < 1e-4 and rel_err(wts[w, :k], out["weights"]) < 1e-4
+        assert rel_err(resid[w], res) < 1e-4
+    g = golden("qoperiods_c5")  # the reference itself on window 0 (num=3, thresh 0.1)
+    nrep, nb = counts[0]
+    assert np.array_equal(per[0, :nrep], g["fp_w0_periods"]) and list(keeps[0, :nb]) == list(g["fp_w0_dict_vals"])
+    assert rel_err(nrm[0, :nrep], g["fp_w0_norms"]) < 1e-4 and rel_err(resid[0], g["fp_w0_residual"]) < 1e-4

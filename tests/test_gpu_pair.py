@@ -1,0 +1,168 @@
+"""m_best step 1 through the window-pair float screen (k_mbest_step1_pair): the screen must be provably
+conservative -- the period lists are the ones the fp64 comparison gives, whatever the float values say.
+
+  * the pair kernel against the one-window fp64 kernel (PH_STEP1_PAIR=0) on odd batches, several lengths, both norms;
+  * two candidates planted INSIDE the float radius (their exact norms differ by 1e-9 relative, the screen cannot
+    tell them apart): the kernel must follow the oracle on both sides of the crossing;
+  * hundreds of survivors (list overflow -> every period exactly), non-finite and zero windows, tiny and huge scales.
+"""
+
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import period_oracle as po
+from pyperiod_amd.synth import multi_sinusoid_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def engines():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import PeriodEngine
+
+    old = os.environ.get("PH_STEP1_PAIR")
+    os.environ["PH_STEP1_PAIR"] = "0"
+    single = PeriodEngine(0)
+    os.environ["PH_STEP1_PAIR"] = "1"
+    pair = PeriodEngine(0)
+    if old is None:
+        del os.environ["PH_STEP1_PAIR"]
+    else:
+        os.environ["PH_STEP1_PAIR"] = old
+    assert pair.m_best_info(4096, 10) == (2, 8) and single.m_best_info(4096, 10) == (1, 8)
+    yield single, pair
+    single.close()
+    pair.close()
+
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
+def test_pair_kernel_equals_one_window_kernel(engines):
+    single, pair = engines
+    for n, w, kw in (
+        (4096, 7, dict(num=10)),
+        (4096, 4, dict(num=6, gamma=True)),
+        (1000, 5, dict(num=5, max_length=499, min_length=3)),
+        (1000, 1, dict(num=4, gamma=True, max_length=900)),
+        (97, 3, dict(num=3)),
+        (6000, 2, dict(num=4)),
+        (240, 9, dict(num=12, max_length=60)),
+    ):
+        x = multi_sinusoid_batch(50 + n, w, n)
+        a = single.m_best(x, want_sweeps=True, **kw)
+        b = pair.m_best(x, want_sweeps=True, **kw)
+        assert np.array_equal(a[0], b[0]), (n, kw)
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert rel_err(b[1], a[1]) < 1e-13 and rel_err(b[2], a[2]) < 1e-13
+
+
+def _planted(n, p, q, b, seed=3):
+    t = np.arange(n, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    sp = rng.standard_normal(p)[t.astype(int) % p]
+    sq = rng.standard_normal(q)[t.astype(int) % q]
+    return sp + b * sq + 1e-3 * rng.standard_normal(n)
+
+
+def test_two_candidates_inside_the_float_radius(engines):
+    """Periods 305 (= 5 x 61) and 335 (= 5 x 67) carry the two planted components; the amplitude of the second is tuned by
+    bisection on the ORACLE until the two exact norms cross, then set 1e-9 (relative, in the norm) to either side:
+    1e4 times closer than the float screen can resolve, 1e5 times wider than an fp64 tie."""
+    _, pair = engines
+    n, p, q = 1024, 61, 67
+
+    def gap(b):
+        v = po.sweep_norms(_planted(n, p, q, b), 2, n // 3)
+        fam_p = max(v[k * p - 2] for k in range(1, n // 3 // p + 1))
+        fam_q = max(v[k * q - 2] for k in range(1, n // 3 // q + 1))
+        return fam_q - fam_p, max(fam_p, fam_q)
+
+    lo, hi = 0.5, 2.0
+    assert gap(lo)[0] < 0 < gap(hi)[0]
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if gap(mid)[0] < 0:
+            lo = mid
+        else:
+            hi = mid
+    seen = set()
+    for b in (lo * (1 - 2e-9), lo * (1 - 2e-8), hi * (1 + 2e-9), hi * (1 + 2e-8)):
+        x = _planted(n, p, q, b)
+        g, top = gap(b)
+        assert 1e-12 < abs(g) / top < 1e-6  # inside the float radius, far outside an fp64 tie
+        for num in (1, 3):
+            want = po.m_best(x, num)
+            per, pw, bs, st = pair.m_best(x[None, :], num)
+            assert st[0] == 0 and np.array_equal(per[0], want[0]), (b, num, per[0], want[0])
+            assert rel_err(pw[0], want[1]) < TOL and rel_err(bs[0], want[2]) < TOL
+        seen.add(int(po.m_best(x, 1)[0][0]) % p == 0)
+    assert seen == {True, False}  # the winner really changes sides
+
+
+def test_survivor_list_overflow_takes_every_period_exactly(engines):
+    """A period-4 signal plus noise of 1e-5: the ~340 multiples of 4 differ by ~1e-10 in the norm -- all of them
+    survive the float screen, the list overflows, and the kernel evaluates every period in fp64."""
+    single, pair = engines
+    n = 4096
+    rng = np.random.default_rng(11)
+    x = np.tile(np.array([1.0, -0.3, 0.55, 0.2]), n // 4) + 1e-5 * rng.standard_normal(n)
+    xb = np.stack([x, multi_sinusoid_batch(3, 1, n)[0], x[::-1].copy()])
+    a = single.m_best(xb, 4, want_sweeps=True)
+    b = pair.m_best(xb, 4, want_sweeps=True)
+    want = [po.m_best(row, 4) for row in xb]
+    for w in range(3):
+        assert np.array_equal(b[0][w], want[w][0]), w
+        assert rel_err(b[1][w], want[w][1]) < TOL and rel_err(b[2][w], want[w][2]) < TOL
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[4], b[4])
+
+
+def test_degenerate_and_extreme_scale_windows(engines):
+    single, pair = engines
+    n = 2048
+    base = multi_sinusoid_batch(70, 6, n)
+    xb = base.copy()
+    xb[1] = 0.0  # no positive norm: status 1, like the one-window kernel
+    xb[2] *= 2.0 ** 600  # squares overflow a double: not screened, every period exactly
+    xb[3] *= 2.0 ** -500
+    xb[4] *= 2.0 ** 90  # far outside the float range before scaling
+    xb[5, 100] = np.nan
+    a = single.m_best(xb, 5, want_sweeps=True)
+    b = pair.m_best(xb, 5, want_sweeps=True)
+    assert np.array_equal(a[3], b[3]) and b[3][1] == 1 and b[3][0] == 0
+    for w in (0, 3, 4):
+        assert np.array_equal(a[0][w], b[0][w]), w
+        want = po.m_best(xb[w], 5)
+        assert np.array_equal(b[0][w], want[0]) and rel_err(b[1][w], want[1]) < TOL and rel_err(b[2][w], want[2]) < TOL
+    # exact power-of-two scaling leaves the period list alone
+    assert np.array_equal(b[0][3], pair.m_best(base[3:4], 5)[0][0]) and np.array_equal(b[0][4], pair.m_best(base[4:5], 5)[0][0])
+    assert np.array_equal(a[0][2], b[0][2]) and np.array_equal(a[0][5], b[0][5])
+
+
+def test_residual_collapse_renews_the_float_scale(engines):
+    """An exactly periodic window: after the first subtraction the residual is rounding noise (1e-16 of the data),
+    the float image is rescaled, and the following picks still agree with the one-window kernel."""
+    single, pair = engines
+    n = 3000
+    rng = np.random.default_rng(5)
+    x = np.tile(rng.standard_normal(75), n // 75)[None, :] + 0.0
+    xb = np.concatenate([x, multi_sinusoid_batch(9, 1, n)])
+    a = single.m_best(xb, 3, want_sweeps=True)
+    b = pair.m_best(xb, 3, want_sweeps=True)
+    # the multiples of 75 tie exactly in exact arithmetic: which one wins is decided by rounding
+    assert a[0][0][0] % 75 == 0 and b[0][0][0] % 75 == 0
+    assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[3], b[3])
+    want = po.m_best(xb[1], 3)
+    assert np.array_equal(b[0][1], want[0]) and rel_err(b[2][1], want[2]) < TOL

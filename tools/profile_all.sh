@@ -3,10 +3,11 @@
 #   tools/profile_all.sh <out-subdir-of-gpurun_out> [groups...]
 # -> hip-event timings, kernel_stats.csv (--kernel-trace --stats) and pmc_summary.csv
 #    (FETCH_SIZE / WRITE_SIZE / SQ counters, separate passes, program directly after `--`).
-R=$PWD
-O=$R/gpurun_out/$1; shift
+[ -n "$1" ] || { echo "usage: tools/profile_all.sh <out-subdir-of-gpurun_out> [groups...]"; exit 2; }
+R="$PWD"
+O="$R/gpurun_out/$1"; shift
 G="$@"
-rm -rf $O; mkdir -p $O
+rm -rf "$O"; mkdir -p "$O"
 python3 tools/profile_all.py --reps 3 --json $O/hip_events.json $G > $O/hip_events.log 2>&1 || { tail -5 $O/hip_events.log; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/tools/profile_all.py --reps 3 $G > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }

@@ -63,3 +63,25 @@ else:
         print(",".join(str(v) for v in r))
 with open(os.path.join(d, "traffic.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)
+# --merge <profiles/traffic.json> --source <label>: record these measurements for bench.py, stamped with the hash
+# of the kernel sources they were measured on (bench.py prints traffic: null for any other build).  Run it in
+# the same gpurun call as the capture, so that the tree is the one that was profiled.
+if "--merge" in sys.argv:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash
+
+    dst = sys.argv[sys.argv.index("--merge") + 1]
+    label = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else d
+    try:
+        with open(dst) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        rec = {}
+    rec.setdefault("format", "kernels: {kernel name: {hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, csrc_hash, ...}}")
+    rec.setdefault("kernels", {})
+    h = csrc_hash()
+    for k, v in traffic.items():
+        if v["hbm_bytes_per_launch"] == v["hbm_bytes_per_launch"]:  # not NaN
+            rec["kernels"][k] = dict(v, source=label, csrc_hash=h)
+    with open(dst, "w") as fh:
+        json.dump(rec, fh, indent=1)
