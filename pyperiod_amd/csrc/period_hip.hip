@@ -82,7 +82,6 @@ struct ph_ctx {
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   int step1_block = 0;               // k_mbest_step1 only: 0 = automatic (PH_STEP1_BLOCK overrides, <= 1024)
   int qo_block = 1024;               // k_qo_find threads per workgroup (PH_QO_BLOCK overrides)
-  int qo_panel = 0;                  // PH_QO_PANEL: cap on the Cholesky block width (0 = as wide as LDS allows, <= 32)
   bool qo_hbm_window = false;        // PH_QO_HBM_WINDOW=1: keep the residual of k_qo_find in HBM even when it fits LDS
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
@@ -416,36 +415,33 @@ using ph::kPad;
 using ph::kMaxWaves;
 using ph::kRedDoubles;
 
-// LDS layout of k_qo_find: bookkeeping, solve vector, then the block columns of the right-looking
-// Cholesky (pan_cap doubles: as many columns of K + 1 rows as fit, at most kQoNb).  The residual window
-// stays in LDS when at least `min_cols` columns of a full dictionary (kcap rows) fit beside it; otherwise
-// (long windows, large dictionaries) it moves to the HBM workspace and the sweeps read it through L2.
-int qo_lds_layout(ph_ctx* c, size_t sz, int N, int max_length, int kcap, size_t* lds_out, int* pan_cap_out,
-                  bool* lds_window_out) {
+// LDS layout of k_qo_find: bookkeeping, the pair table, the weights, and the six work vectors + sample counts of the
+// conjugate-gradient solve (one slot per dictionary row and one per block).  The residual window stays in LDS when
+// it fits; the work vectors then OVERLAY it if it is large enough (the window is dead during a solve) -- 79 KB per
+// workgroup for N = 16384 fp32 with kcap = 1024, two workgroups per CU -- and sit behind it otherwise.  Windows
+// that do not fit (long fp64 windows) move to the HBM workspace and the sweeps read them through L2.
+int qo_lds_layout(ph_ctx* c, size_t sz, int N, int max_length, int kcap, size_t* lds_out, bool* lds_window_out,
+                  bool* overlay_out) {
+  const size_t kv = (size_t)kcap + ph::kQoMaxBlocks;
   const size_t fixed = carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) + carve_bytes(kMaxWaves, 4) +
                        2 * carve_bytes(ph::kQoMaxBlocks, 4) + carve_bytes(ph::kQoMaxBlocks + 1, 4) +
                        carve_bytes(ph::kQoMaxBlocks, 8) + carve_bytes((max_length + 32) / 32, 4) +
-                       carve_bytes(kcap, 8) + carve_bytes(ph::kQoNb, 8) + carve_bytes(4, 4);
+                       carve_bytes(2 * ph::kQoPairTab * ph::kQoPairTab, 4) + carve_bytes(ph::kQoMaxBlocks, 4) +
+                       carve_bytes(ph::kQoMaxBlocks + 1, 4) + carve_bytes(6 * kMaxWaves, 8) + carve_bytes(kv, 8);
+  const size_t solver = 6 * carve_bytes(kv, 8) + carve_bytes(kv, 4);
   const size_t win = carve_bytes(N + kPad, sz);
-  const size_t ldp = (size_t)((kcap + 1) | 1);
   const size_t limit = (size_t)c->lds_limit;
-  auto columns = [&](size_t used) { return limit > used + 64 ? (limit - used - 64) / (ldp * 8) : 0; };
-  const size_t min_cols = 16;  // narrower blocks multiply the trailing-update traffic (K^3 / (3 nb) elements)
-  const bool lds_window = !c->qo_hbm_window && fixed + win <= limit && columns(fixed + win) >= min_cols;
-  const size_t used = fixed + (lds_window ? win : 0);
-  size_t cols = std::min<size_t>(columns(used), ph::kQoNb);
-  if (c->qo_panel) cols = std::min<size_t>(cols, (size_t)c->qo_panel);
-  if (cols < 1)
-    return fail(PH_E_ARG, "ph_qo_find_periods: kcap=%d leaves no LDS for a Cholesky block column (limit %d B)", kcap,
-                c->lds_limit);
-  // all the LDS that is left: smaller dictionaries (K < kcap) get wider blocks
-  const size_t pan_cap = c->qo_panel ? cols * ldp : (limit - used - 64) / 8;
-  *lds_out = used + carve_bytes(pan_cap, 8);
-  *pan_cap_out = (int)pan_cap;
+  if (fixed + solver > limit)
+    return fail(PH_E_ARG, "ph_qo_find_periods: kcap=%d needs %zu B of LDS for the solver (limit %d B)", kcap,
+                fixed + solver, c->lds_limit);
+  const bool overlay = win >= solver;
+  const size_t with_window = fixed + (overlay ? win : win + solver);
+  const bool lds_window = !c->qo_hbm_window && with_window <= limit;
+  *lds_out = lds_window ? with_window : fixed + solver;
   *lds_window_out = lds_window;
+  *overlay_out = lds_window && overlay;
   return PH_OK;
 }
-
 
 // LDS of k_mbest_step1_pair: the pair window, one fp64 staging buffer, bookkeeping of two windows.
 size_t pair_lds_bytes(int N, int num, int P) {
@@ -527,7 +523,6 @@ int ph_create(int device, ph_ctx** out) {
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->qo_block = v;
   }
   if (std::getenv("PH_QO_HBM_WINDOW")) c->qo_hbm_window = true;
-  if (const char* e = std::getenv("PH_QO_PANEL")) c->qo_panel = std::max(1, std::min(32, std::atoi(e)));
   if (const char* e = std::getenv("PH_SWEEP_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 512 && v % 64 == 0) c->sweep_block = v;
@@ -1444,9 +1439,8 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   size_t lds;
-  int pan_cap;
-  bool lds_window;
-  PH_TRY(qo_lds_layout(c, sz, N, max_length, kcap, &lds, &pan_cap, &lds_window));
+  bool lds_window, overlay;
+  PH_TRY(qo_lds_layout(c, sz, N, max_length, kcap, &lds, &lds_window, &overlay));
   void* gwin = nullptr;
   if (!lds_window) {
     PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * ph::win_stride(N + kPad) * sz));
@@ -1474,8 +1468,7 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_TRY(upload_table(c, T_AUX0, phi.data(), phi.size(), &d_phi));
   PH_TRY(upload_table(c, T_AUX1, off.data(), off.size(), &d_off));
   PH_TRY(upload_table(c, T_AUX2, dq.data(), dq.size(), &d_dq));
-  const size_t ws_per = 2 * (size_t)kcap * kcap + 4 * (size_t)kcap;
-  PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * ws_per * sizeof(double)));
+  PH_TRY(ensure(c, c->buf[B_WS1], (size_t)W * 2 * kcap * sizeof(double)));  // last good weights + rhs of every window
   Stage st(c, flags);
   const void* dx;
   void *dper, *dnrm, *dkeep, *dcnt, *dwts, *dres, *dstat;
@@ -1494,7 +1487,7 @@ int ph_qo_find_periods(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
     PH_TRY(allow_lds(kernel, lds));
     ProfScope ps_(c, "k_qo_find");
     hipLaunchKernelGGL(kernel, grid, dim3(c->qo_block), lds, c->stream, (const T*)dx, N, num, thresh, min_length,
-                       max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, pan_cap, (T*)gwin, (double*)c->buf[B_WS1].p,
+                       max_length, geom, plan, n_pass, d_phi, d_off, d_dq, kcap, overlay ? 1 : 0, (T*)gwin, (double*)c->buf[B_WS1].p,
                        (uint32_t*)dper, (double*)dnrm, (int*)dkeep, (int*)dcnt, (double*)dwts, (T*)dres, (int*)dstat);
     return (int)PH_OK;
   }));
@@ -1508,9 +1501,8 @@ int ph_qo_feasible(ph_ctx* c, int dtype, int N, int max_length, int kcap, int* o
   if (N < 1 || kcap < 1 || kcap > 2048) return PH_OK;
   if (max_length < 0) max_length = N / 3;
   size_t lds;
-  int pan_cap;
-  bool lds_window;
-  if (qo_lds_layout(c, elem_size(dtype), N, max_length, kcap, &lds, &pan_cap, &lds_window) == PH_OK) *ok = 1;
+  bool lds_window, overlay;
+  if (qo_lds_layout(c, elem_size(dtype), N, max_length, kcap, &lds, &lds_window, &overlay) == PH_OK) *ok = 1;
   return PH_OK;
 }
 

@@ -1970,22 +1970,101 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 // singular).  counts[w] = {periods reported, blocks in the dictionary}.
 // ======================================================================================
 constexpr int kQoMaxBlocks = 64;
+constexpr int kQoPairTab = 16;  // dictionaries of up to this many blocks keep their pair constants in LDS
 
-constexpr int kQoNb = 32;  // widest block of the right-looking Cholesky (columns held in LDS)
+// sums of two values over the workgroup with one pair of barriers (every thread gets both)
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+  const int tid = threadIdx.x;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((tid & (kWave - 1)) == 0) {
+    red[tid >> 6] = a;
+    red[kMaxWaves + (tid >> 6)] = b;
+  }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+  for (int i = 0; i < nw; ++i) {
+    ta += red[i];
+    tb += red[kMaxWaves + i];
+  }
+  __syncthreads();
+  a = uniform_f64(ta);
+  b = uniform_f64(tb);
+}
+
+__device__ __forceinline__ int qo_gcd(int a, int b) {
+  while (b != 0) {
+    const int t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+// Off-diagonal part of one row of the Gram matrix A A^T times a vector, WITHOUT the matrix.  Row (a, i) is the
+// indicator of n = i (mod p_a); its entry against row (b, j) counts the n < N with n = i (p_a) and n = j (p_b)
+// (QOPeriods.py:781).  Along n = i, i + p_a, ... the residue mod p_b advances by p_a mod p_b and returns after
+// cycle = p_b / gcd steps, so
+//   sum_j G[(a,i),(b,j)] v_b[j] = sum_{t < min(cycle, terms)} count(t) v_b[idx_t],   count(t) = (terms-1-t) / cycle + 1,
+// with terms = samples of residue i.  For N < lcm(p_a, p_b) every count is 1 and the loop is the fold of the tiled
+// v_b.  The steps t = t0, t0 + ts, ... are summed (a group of `ts` lanes shares a long row).
+__device__ __forceinline__ int qo_wrap(int idx, int pb) {  // idx in [0, 2 pb) -> idx mod pb
+  return (int)min((unsigned)idx, (unsigned)(idx - pb));
+}
+
+// `vb` points at block b's entries inside a vector in the solver's layout: k_b entries followed by one zero, so an
+// index past the kept rows is clamped onto the zero instead of being masked.
+__device__ __forceinline__ double qo_offdiag(const double* __restrict__ vb, int kb, int pb, int cycle, int step, int i,
+                                             int terms, int t0, int ts) {
+  const int lim = cycle < terms ? cycle : terms;
+  if (t0 >= lim) return 0.0;
+  int idx = (int)(((unsigned)i + (unsigned)t0 * (unsigned)step) % (unsigned)pb);  // i < 2^20, t0 < 16, step < p_b < 2^20
+  const int sstep = ts == 1 ? step : (int)(((unsigned)ts * (unsigned)step) % (unsigned)pb);
+  if (cycle >= terms) {  // all counts are 1
+    double s0 = 0.0, s1 = 0.0;
+    int t = t0;
+    for (; t + 3 * ts < lim; t += 4 * ts) {
+      const int i1 = qo_wrap(idx + sstep, pb), i2 = qo_wrap(i1 + sstep, pb), i3 = qo_wrap(i2 + sstep, pb);
+      const double v0 = vb[min(idx, kb)], v1 = vb[min(i1, kb)], v2 = vb[min(i2, kb)], v3 = vb[min(i3, kb)];
+      s0 += v0;
+      s1 += v1;
+      s0 += v2;
+      s1 += v3;
+      idx = qo_wrap(i3 + sstep, pb);
+    }
+    for (; t < lim; t += ts) {
+      s0 += vb[min(idx, kb)];
+      idx = qo_wrap(idx + sstep, pb);
+    }
+    return s0 + s1;
+  }
+  const int chi = (terms - 1) / cycle + 1, tsw = (terms - 1) % cycle;
+  double shi = 0.0, slo = 0.0;
+  for (int t = t0; t < lim; t += ts) {
+    const double v = vb[min(idx, kb)];
+    if (t <= tsw)
+      shi += v;
+    else
+      slo += v;
+    idx = qo_wrap(idx + sstep, pb);
+  }
+  return (double)chi * shi + (double)(chi - 1) * slo;
+}
 
 template <typename T, bool LW>
 __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
                                                         int p_lo, int p_hi, const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
                                                         const int* __restrict__ phi, const int* __restrict__ div_off,
-                                                        const int* __restrict__ div_q, int kcap, int pan_cap, T* gwin,
+                                                        const int* __restrict__ div_q, int kcap, int overlay, T* gwin,
                                                         double* __restrict__ ws_all, uint32_t* __restrict__ periods_out,
                                                         double* __restrict__ norms_out, int* __restrict__ keeps_out,
                                                         int* __restrict__ counts_out, double* __restrict__ weights_out,
                                                         T* __restrict__ resid_out, int* __restrict__ status_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  // the residual: LDS, or (LW == false: long windows, or LDS given to the solver) the HBM workspace
+  // the residual: LDS, or (LW == false: windows that leave no room for the solver's vectors) the HBM workspace
   T* work = window_buf<T, LW>(cv, gwin, N + kPad);
   double* red = cv.take<double>(kRedDoubles);
   double* wbest = cv.take<double>(kMaxWaves);
@@ -1995,10 +2074,25 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
   int* boff = cv.take<int>(kQoMaxBlocks + 1);   // first row of block b
   double* bnorm = cv.take<double>(kQoMaxBlocks);
   uint32_t* seen = cv.take<uint32_t>((p_hi + 32) / 32);  // running divisor set R (QOPeriods.py:832-835)
-  double* yv = cv.take<double>(kcap);  // solve vector
-  double* dsum = cv.take<double>(kQoNb);
-  int* sing_flag = cv.take<int>(4);
-  double* pan = cv.take<double>((size_t)pan_cap);  // block columns of the factorisation (stride (K + 1) | 1, odd)
+  int* ptab = cv.take<int>(2 * kQoPairTab * kQoPairTab);  // (a, b): {p_b / gcd(p_a, p_b), p_a mod p_b}
+  double* red3 = cv.take<double>(6 * kMaxWaves);  // wave partials of the solver's fused reduction (two parities)
+  int* blg = cv.take<int>(kQoMaxBlocks);        // log2 of the lanes that share a row of block b in the product
+  int* ioff = cv.take<int>(kQoMaxBlocks + 1);   // first work item of block b
+  // Conjugate gradients on A A^T w = A x.  Solver layout of a vector: block b's k_b entries start at slot
+  // boff[b] + b and are followed by one zero (qo_offdiag clamps indices past the kept rows onto it).
+  const int kv = kcap + kQoMaxBlocks;
+  double* xv = cv.take<double>(kv);  // weights; persistent: the rows of earlier steps start from their last values
+  // The other vectors only live during a solve, when the residual window is dead (it is rebuilt from the data and the
+  // reconstruction afterwards): they overlay the window buffer when that is large enough, which leaves room for a
+  // second workgroup on the CU.
+  Carve sv((LW && overlay) ? reinterpret_cast<unsigned char*>(work) : cv.base + cv.off);
+  double* rv = sv.take<double>(kv);   // residual of the normal equations (starts as A x, QOPeriods.py:782)
+  double* pv = sv.take<double>(kv);   // search direction
+  double* qv = sv.take<double>(kv);   // A A^T pv
+  double* zv = sv.take<double>(kv);   // preconditioned residual
+  double* wv_ = sv.take<double>(kv);  // A A^T zv
+  double* dv = sv.take<double>(kv);   // 1 / diagonal = 1 / samples of the row's residue (Jacobi preconditioner)
+  int* trm = sv.take<int>(kv);        // samples of the row's residue
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -2006,11 +2100,8 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const T* data = x + w * (int64_t)N;
-  double* G = ws_all + w * (2 * (int64_t)kcap * kcap + 4 * (int64_t)kcap);  // Gram, column-major, ld = kcap
-  double* L = G + (int64_t)kcap * kcap;                                      // Cholesky factor, ld = kcap + 1
-  double* rhs = L + (int64_t)(kcap + 1) * kcap;
-  double* wts = rhs + kcap;  // last good weights
-  double* ysv = wts + kcap;  // y = L^-1 rhs of the rows factored so far (kept across the greedy steps)
+  double* wts = ws_all + w * 2 * (int64_t)kcap;  // last good weights (row order)
+  double* rhs = wts + kcap;                      // A x of the rows found so far
 
   load_window(data, work, N);
   zero_pad(work, N);
@@ -2024,8 +2115,9 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
   bool stopped_by_test = false;
 
 #ifdef PH_QO_TIMERS
-  long long tq[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tq0 = wall_clock64();
+  int cg_iters = 0;
 #define PH_QO_MARK(k)                         \
   {                                           \
     const long long now_ = wall_clock64();    \
@@ -2109,39 +2201,18 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
       boff[nb + 1] = row0 + keep;
       bnorm[nb] = best;
     }
-    __syncthreads();
-    const int K = row0 + keep;
-    // ---- Gram columns of the new block: G[(a,i),(nb,j)] = #{n < N : n = i (mod p_a), n = j (mod p)}.
-    //      Along n = j, j+p, j+2p, ... the residue mod p_a cycles with period p_a / gcd(p_a, p), so
-    //      each entry is a closed-form count; no read-modify-write on HBM.
-    for (int e = tid; e < K * keep; e += blockDim.x) G[(int64_t)(row0 + e / K) * kcap + e % K] = 0.0;
-    __threadfence_block();
-    __syncthreads();
-    for (int j = tid; j < keep; j += blockDim.x) {
-      double* col = G + (int64_t)(row0 + j) * kcap;  // column (nb, j); thread j owns it
-      const int terms = (N - 1 - j) / bestp + 1;     // samples n = j (mod p) below N
-      for (int b = 0; b <= nb; ++b) {
-        const int pa = bper[b], ka = bkeep[b], oa = boff[b];
-        int g = pa, h = bestp % pa;
-        while (h != 0) {
-          const int t = g % h;
-          g = h;
-          h = t;
-        }
-        const int cycle = pa / g;
-        int i = j % pa;
-        const int step = bestp % pa;
-        const int lim = cycle < terms ? cycle : terms;
-        for (int t0 = 0; t0 < lim; ++t0) {
-          if (i < ka) col[oa + i] = (double)((terms - 1 - t0) / cycle + 1);
-          i += step;
-          if (i >= pa) i -= pa;
-        }
+    // pair constants of the new block against every block (and itself: unused)
+    if (nb < kQoPairTab) {
+      for (int e = tid; e < nb; e += blockDim.x) {
+        const int pe = bper[e], g = qo_gcd(pe, bestp);
+        ptab[2 * (e * kQoPairTab + nb)] = bestp / g;  // row in block e against block nb
+        ptab[2 * (e * kQoPairTab + nb) + 1] = pe % bestp;
+        ptab[2 * (nb * kQoPairTab + e)] = pe / g;
+        ptab[2 * (nb * kQoPairTab + e) + 1] = bestp % pe;
       }
     }
-    PH_QO_MARK(1)
-    // right-hand side: fold of the data (QOPeriods.py:782), one wavefront per residue (a small period
-    // has few residues with many samples each: two threads summing 8192 samples cost 0.2 ms)
+    // right-hand side rows of the new block: fold of the data (QOPeriods.py:782), one wavefront per residue (a
+    // small period has few residues with many samples each)
     for (int j = wv; j < keep; j += nw) {
       const int terms = (N - 1 - j) / bestp + 1;
       double sj = 0.0;
@@ -2151,261 +2222,234 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
     }
     __threadfence_block();
     __syncthreads();
-    PH_QO_MARK(2)
-    // mirror the new columns into the old columns' new rows
-    for (int e = tid; e < row0 * keep; e += blockDim.x) {
-      const int r = e % row0, j = e / row0;
-      G[(int64_t)r * kcap + (row0 + j)] = G[(int64_t)(row0 + j) * kcap + r];
+    PH_QO_MARK(1)
+    const int K = row0 + keep;
+    const int nblk = nb + 1;
+    const int KS = K + nblk;  // slots
+    // the window buffer is dead from here to the reconstruction: set the solver's vectors up in it
+    for (int sl = tid; sl < KS; sl += blockDim.x) {
+      int a = 0;
+      while (a + 1 < nblk && boff[a + 1] + a + 1 <= sl) ++a;
+      const int i = sl - boff[a] - a;
+      const bool pad = i >= bkeep[a];  // the zero behind block a
+      const int r = boff[a] + i;
+      const int terms = pad ? 1 : (N - 1 - i) / bper[a] + 1;
+      trm[sl] = terms;
+      dv[sl] = pad ? 0.0 : 1.0 / (double)terms;
+      rv[sl] = pad ? 0.0 : rhs[r];  // the right-hand side, until the first product turns it into the residual
+      wv_[sl] = 0.0;  // (the product never writes the pad slots)
+      qv[sl] = 0.0;
+      if (pad || r >= row0) xv[sl] = 0.0;  // the rows of earlier steps start from their last weights
     }
-    __threadfence_block();
-    __syncthreads();
-    PH_QO_MARK(3)
-    // ---- G = L L^T, L y = rhs, L^T w = y.  Right-looking blocked Cholesky of the augmented matrix
-    //      [G; rhs^T] (the rhs is carried as row K of every column, it leaves the factorisation as y),
-    //      a block of <= NB columns at a time.  The block's columns (all rows below the diagonal) sit in
-    //      LDS: one wavefront factors the diagonal block, every thread then solves one row against it in
-    //      registers, and the trailing matrix is updated in a single sweep -- every element read and
-    //      written once per block, 4 columns x 2 rows per lane, coalesced.
-    //      Bordered: the factor of the rows found in earlier greedy steps (and their y) is kept; only the
-    //      rows of the new dictionary block are copied in and reduced -- the old block columns skip the
-    //      diagonal factorisation and touch the new rows only (-25 % of the work of refactoring from scratch).
-    bool singular = false;
-    {
-      const int ldl = kcap + 1;  // factor workspace: column-major, rows 0..K-1 then the rhs row
-      const int ldp = (K + 1) | 1;
-      const int nbmax = min(kQoNb, pan_cap / ldp);
-      // new rows (and the rhs slot, row K) of every column; the rhs slot of an old column holds its final y
-      for (int e = tid; e < K * (keep + 1); e += blockDim.x) {
-        const int c = e / (keep + 1), r = row0 + (e - c * (keep + 1));
-        if (r >= c) L[(int64_t)c * ldl + r] = r < K ? G[(int64_t)c * kcap + r] : (c < row0 ? ysv[c] : rhs[c]);
-      }
-      if (tid == 0) *sing_flag = 0;
-      __threadfence_block();
-      __syncthreads();
-      PH_QO_MARK(8)
-      for (int J = 0, jb = 0; J < K; J += jb) {
-        const bool old = J < row0;  // block column of an earlier greedy step: already final above row0
-        jb = old ? min(nbmax, row0 - J) : min(nbmax, K - J);
-        const int nr = K - J + 1;  // rows J .. K-1 and the rhs row
-        const int rnew = old ? row0 - J : 0;  // first panel row this step still has to produce
-        for (int e = tid; e < nr * jb; e += blockDim.x) {
-          const int cc = e / nr, rr = e - cc * nr;
-          pan[cc * ldp + rr] = rr >= cc ? L[(int64_t)(J + cc) * ldl + J + rr] : 0.0;
+    // Work split of the product: a row of block a costs sum_b min(cycle_ab, samples) steps -- the rows of short
+    // periods are the long ones.  Block a gets L_a = 1, 2, ..., 16 lanes per row so that no lane walks more than
+    // ~1/1024 of all steps; the lanes of a row are neighbours and combine with DPP.
+    if (tid == 0) {
+      long long total = 0;
+      int steps[kQoMaxBlocks];
+      for (int a = 0; a < nblk; ++a) {
+        const int pa = bper[a], terms = (N - 1) / pa + 1;
+        int st = 0;
+        for (int b = 0; b < nblk; ++b) {
+          if (b == a) continue;
+          const int cyc = bper[b] / qo_gcd(pa, bper[b]);
+          st += cyc < terms ? cyc : terms;
         }
-        __syncthreads();
-        PH_QO_MARK(9)
-        if (wv == 0 && !old) {  // diagonal block jb x jb (jb <= 32), one wavefront, lane = row, left-looking:
-          // column cc of row r is a dot product over the finished columns -- reads only, no
-          // read-modify-write chains through LDS
-          for (int cc = 0; cc < jb; ++cc) {
-            const bool act = lane >= cc && lane < jb;
-            double v = 0.0;
-            if (act) {
-              v = pan[cc * ldp + lane];
-              int c2 = 0;
-              for (; c2 + 8 <= cc; c2 += 8) {  // eight independent pairs of LDS reads per wait
-                double a[8], b[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  a[u] = pan[(c2 + u) * ldp + lane];
-                  b[u] = pan[(c2 + u) * ldp + cc];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v = fma(-a[u], b[u], v);
-              }
-              for (; c2 < cc; ++c2) v = fma(-pan[c2 * ldp + lane], pan[c2 * ldp + cc], v);
+        steps[a] = st;
+        total += (long long)st * bkeep[a];
+      }
+      // greedy: give the block with the longest walk twice the lanes while all items still fit one round of the
+      // workgroup (blocks of periods below 64 always get 16 lanes: their rows have up to N / 2 samples)
+      int items = 0;
+      for (int a = 0; a < nblk; ++a) {
+        blg[a] = bper[a] < 64 ? 4 : 0;
+        items += ((bkeep[a] << blg[a]) + 15) & ~15;
+      }
+      (void)total;
+      for (;;) {
+        int worst = -1, wst = 24;
+        for (int a = 0; a < nblk; ++a)
+          if (blg[a] < 4 && (steps[a] >> blg[a]) > wst) {
+            wst = steps[a] >> blg[a];
+            worst = a;
+          }
+        if (worst < 0) break;
+        const int grown = items - (((bkeep[worst] << blg[worst]) + 15) & ~15) + (((bkeep[worst] << (blg[worst] + 1)) + 15) & ~15);
+        if (grown > (int)blockDim.x) break;
+        items = grown;
+        blg[worst] += 1;
+      }
+      int off = 0;
+      for (int a = 0; a < nblk; ++a) {
+        ioff[a] = off;
+        off += ((bkeep[a] << blg[a]) + 15) & ~15;  // groups never straddle a 16-lane DPP row
+      }
+      ioff[nblk] = off;
+    }
+    __syncthreads();
+    // ---- A A^T w = A x by preconditioned conjugate gradients.  The Gram matrix (integer co-occurrence counts,
+    //      QOPeriods.py:781) is never formed: its rows are regenerated from the CRT structure inside the product
+    //      (qo_offdiag), so the solve touches LDS only -- a dense factorisation of the K x K matrix (K up to ~900,
+    //      5 MB) streamed it through HBM K / 32 times.  The diagonal blocks are diagonal (samples per residue); with
+    //      that as preconditioner the spectrum is a cluster at 1 plus a few small eigenvalues from the mean /
+    //      common-divisor directions the blocks share: 20-70 iterations to 1e-13.
+    // With `dots`, the lane that finishes a row also accumulates that row's terms of gamma = (r, z), delta = (w, z)
+    // and |r|^2 (vv is z then), so the three sums need no pass of their own.
+    double dg = 0.0, dd = 0.0, dr = 0.0;
+    auto gram_apply = [&](const double* __restrict__ vv, double* __restrict__ out, bool dots) {
+      const int nitems = ioff[nblk];
+      for (int v = tid; v < nitems; v += blockDim.x) {
+        int a = 0;
+        while (a + 1 < nblk && ioff[a + 1] <= v) ++a;
+        const int lg = blg[a], L = 1 << lg;
+        const int e = v - ioff[a];
+        const int i = e >> lg, gl = e & (L - 1);
+        const int ka = bkeep[a];
+        double acc = 0.0;
+        int terms = 1;
+        const int sl = boff[a] + a + (i < ka ? i : 0);
+        if (i < ka) {  // (the padding items of the last row group only take part in the DPP steps)
+          const int pa = bper[a];
+          terms = trm[sl];
+          for (int b = 0; b < nblk; ++b) {
+            if (b == a) continue;
+            const int pb = bper[b];
+            int cycle, step;
+            if (nblk <= kQoPairTab) {
+              cycle = ptab[2 * (a * kQoPairTab + b)];
+              step = ptab[2 * (a * kQoPairTab + b) + 1];
+            } else {
+              cycle = pb / qo_gcd(pa, pb);
+              step = pa % pb;
             }
-            const double piv = __shfl(v, cc, kWave);
-            if (!(piv > 1e-9)) {  // counts are integers: an independent row leaves a pivot of order 1
-              if (lane == 0) *sing_flag = 1;
-              break;
-            }
-            const double d = sqrt(piv);
-            if (act) pan[cc * ldp + lane] = lane == cc ? d : v / d;
-            ram_wave_sync();
+            acc += qo_offdiag(vv + boff[b] + b, bkeep[b], pb, cycle, step, i, terms, gl, L);
           }
         }
+        if (lg >= 4) acc += dpp_f64<kDppRor8>(acc);
+        if (lg >= 3) acc += dpp_f64<kDppHalfMirror>(acc);
+        if (lg >= 2) acc += dpp_f64<kDppXor2>(acc);
+        if (lg >= 1) acc += dpp_f64<kDppXor1>(acc);
+        if (gl == 0 && i < ka) {
+          const double z = vv[sl], wrow = fma((double)terms, z, acc);
+          out[sl] = wrow;
+          if (dots) {
+            const double t = rv[sl];
+            dg = fma(t, z, dg);
+            dd = fma(wrow, z, dd);
+            dr = fma(t, t, dr);
+          }
+        }
+      }
+    };
+    // Single-reduction form (Chronopoulos / Gear): z = D^-1 r, w = G z, and gamma = (r, z), delta = (w, z), |r|^2
+    // come out of ONE workgroup reduction per iteration; p and q = G p follow by recurrence.
+    bool singular = false;
+    {
+      gram_apply(xv, qv, false);
+      __syncthreads();
+      double bb = 0.0;
+      for (int r = tid; r < KS; r += blockDim.x) {
+        const double bval = rv[r], t = bval - qv[r];
+        rv[r] = t;
+        zv[r] = t * dv[r];
+        bb = fma(bval, bval, bb);
+      }
+      bb = block_sum(bb, red);  // (its barriers also publish zv)
+      const double tol = sizeof(T) == 4 ? 1e-11 : 1e-13;  // ||r|| <= tol ||A x||
+      const double tol2 = tol * tol * bb;
+      const int itmax = 4 * K + 100;
+      double gamma_old = 0.0, alpha = 0.0, rr = 1.0 / 0.0;
+      int iter = 0;
+      for (;; ++iter) {
+        dg = dd = dr = 0.0;
+        gram_apply(zv, wv_, true);
+        // one reduction for the three sums; the partials of odd and even iterations use different slots, so the
+        // only barriers of an iteration are the one here and the one behind the vector updates
+        double* part = red3 + (iter & 1) * 3 * kMaxWaves;
+        const double sg = wave_sum(dg), sd = wave_sum(dd), sr = wave_sum(dr);
+        if (lane == 0) {
+          part[wv] = sg;
+          part[kMaxWaves + wv] = sd;
+          part[2 * kMaxWaves + wv] = sr;
+        }
         __syncthreads();
-        PH_QO_MARK(10)
-        if (*sing_flag) {
+        double g = 0.0, d = 0.0;
+        rr = 0.0;
+        for (int i = 0; i < nw; ++i) {
+          g += part[i];
+          d += part[kMaxWaves + i];
+          rr += part[2 * kMaxWaves + i];
+        }
+        g = uniform_f64(g);
+        d = uniform_f64(d);
+        rr = uniform_f64(rr);
+        if (rr <= tol2 || iter >= itmax) break;
+        const double beta = iter == 0 ? 0.0 : g / gamma_old;
+        const double denom = iter == 0 ? d : d - beta * g / alpha;
+        if (!(denom > 0.0) || !(g > 0.0)) {  // not positive definite: numpy.linalg.solve would raise or return garbage
           singular = true;
           break;
         }
-        // rows below the block (and the rhs row): x D^T = a, forward substitution, 16 columns at a time in
-        // registers; the finished half is folded into the columns of the second half before it is dropped
-        for (int rr = max(jb, rnew) + tid; rr < (old ? nr - 1 : nr); rr += blockDim.x) {
-#pragma unroll 1
-          for (int c_lo = 0; c_lo < jb; c_lo += 16) {
-            double xr[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-              const int cc = c_lo + u;
-              if (cc < jb) {
-                double v = pan[cc * ldp + rr];
-#pragma unroll
-                for (int u2 = 0; u2 < u; ++u2) v = fma(-xr[u2], pan[(c_lo + u2) * ldp + cc], v);
-                xr[u] = v / pan[cc * ldp + cc];
-              } else {
-                xr[u] = 0.0;
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-              if (c_lo + u < jb) pan[(c_lo + u) * ldp + rr] = xr[u];
-            for (int cc = c_lo + 16; cc < jb; ++cc) {  // 16 independent broadcast reads per column
-              double t = pan[cc * ldp + rr];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) t = fma(-xr[u], pan[(c_lo + u) * ldp + cc], t);
-              pan[cc * ldp + rr] = t;
-            }
-          }
+        alpha = g / denom;
+        gamma_old = g;
+        for (int r = tid; r < KS; r += blockDim.x) {
+          const double pn = fma(beta, iter == 0 ? 0.0 : pv[r], zv[r]);
+          const double qn = fma(beta, iter == 0 ? 0.0 : qv[r], wv_[r]);
+          pv[r] = pn;
+          qv[r] = qn;
+          xv[r] = fma(alpha, pn, xv[r]);
+          const double t = fma(-alpha, qn, rv[r]);
+          rv[r] = t;
+          zv[r] = t * dv[r];
         }
         __syncthreads();
-        PH_QO_MARK(11)
-        for (int e = tid; e < nr * jb; e += blockDim.x) {
-          const int cc = e / nr, rr = e - cc * nr;
-          if (rr >= cc) {
-            if (rr < nr - 1) {
-              if (rr >= rnew) L[(int64_t)(J + cc) * ldl + J + rr] = pan[cc * ldp + rr];
-            } else {
-              yv[J + cc] = pan[cc * ldp + rr];  // old columns: their kept y; new ones: just solved
-              if (!old) ysv[J + cc] = pan[cc * ldp + rr];
-            }
-          }
-        }
-        PH_QO_MARK(12)
-        // trailing update: A[i][j] -= sum_c P[i][c] P[j][c] for j >= J + jb, j <= i <= K
-        const int T0 = J + jb;
-        const int rlo = old ? row0 : 0;            // old block columns only reach the new rows
-        const int ngroups = (K - T0 + 3) >> 2;     // 4 columns per item
-        const int maxch = (K + 1 - max(T0, rlo) + 127) >> 7;  // 128-row chunks of the longest column group
-        // items: (column group g, chunk h) with rows from the group's first target row (its diagonal element,
-        // or the first new row); later groups have fewer chunks, their surplus items fall through
-        for (int item = wv; item < ngroups * maxch; item += nw) {
-          const int g = item / maxch, h = item - g * maxch;
-          if (128 * h > K - max(T0 + 4 * g, rlo)) continue;
-          const int j0 = T0 + 4 * g;
-          const int i0 = max(j0, rlo) + 128 * h + lane;  // rows i0, i0 + 64
-          // the old values are requested first: their HBM / L2 latency hides behind the dot products
-          double acc[2][4];
-          bool ok[2][4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int jq = j0 + q;
-            const double* src = L + (int64_t)min(jq, K - 1) * ldl;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int i = i0 + 64 * k;
-              // the rhs slot (row K) of an old column already holds its final y
-              ok[k][q] = jq < K && i >= jq && i <= K && !(i == K && jq < row0);
-              acc[k][q] = ok[k][q] ? src[i] : 0.0;
-            }
-          }
-          const int ra = min(i0 - J, nr - 1), rb = min(i0 + 64 - J, nr - 1);  // clamped panel rows (masked on store)
-          const int cj = j0 - J;
-          const int cq[4] = {min(cj, nr - 1), min(cj + 1, nr - 1), min(cj + 2, nr - 1), min(cj + 3, nr - 1)};
-          int c = 0;
-          for (; c + 4 <= jb; c += 4) {  // 24 LDS reads in flight, then 32 fma
-            double pa[4], pb[4], pj[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double* col = pan + (c + u) * ldp;
-              pa[u] = col[ra];
-              pb[u] = col[rb];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) pj[u][q] = col[cq[q]];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                acc[0][q] = fma(-pa[u], pj[u][q], acc[0][q]);
-                acc[1][q] = fma(-pb[u], pj[u][q], acc[1][q]);
-              }
-          }
-          for (; c < jb; ++c) {
-            const double* col = pan + c * ldp;
-            const double pa = col[ra], pb = col[rb];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const double pj = col[cq[q]];
-              acc[0][q] = fma(-pa, pj, acc[0][q]);
-              acc[1][q] = fma(-pb, pj, acc[1][q]);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            double* dst = L + (int64_t)min(j0 + q, K - 1) * ldl;
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-              if (ok[k][q]) dst[i0 + 64 * k] = acc[k][q];
-          }
-        }
-        __threadfence_block();
-        __syncthreads();
-        PH_QO_MARK(13)
+      }
+      if (!(rr <= tol2)) singular = true;  // no convergence (or not finite): a numerically singular dictionary
+#ifdef PH_QO_TIMERS
+      cg_iters += iter;
+#endif
+    }
+    PH_QO_MARK(2)
+    __syncthreads();
+    if (singular) {
+      // go back one iteration and stop (QOPeriods.py:552-559): the weights return to the last good solve, and the
+      // residual -- the solver's vectors may have overwritten the window -- is rebuilt from them below
+      for (int r = tid; r < row0; r += blockDim.x) {
+        int a = 0;
+        while (a + 1 < nb && boff[a + 1] <= r) ++a;
+        xv[r + a] = wts[r];
+      }
+    } else {
+      nb += 1;
+      for (int r = tid; r < K; r += blockDim.x) {
+        int a = 0;
+        while (a + 1 < nb && boff[a + 1] <= r) ++a;
+        wts[r] = xv[r + a];
       }
     }
-    PH_QO_MARK(4)
-    if (singular) break;  // go back one iteration and stop (QOPeriods.py:552-559)
-    // L^T w = y, blocks from the last one back: the rows below a block are already final -- their
-    // contribution is one wavefront dot product per column --, the diagonal block is solved by one wavefront
-    {
-      const int ldl = kcap + 1;
-      const int ldp = (K + 1) | 1;
-      const int nbmax = min(kQoNb, pan_cap / ldp);
-      for (int jend = K; jend > 0;) {
-        const int jb = min(nbmax, jend), J = jend - jb, nr = K - J;
-        for (int e = tid; e < nr * jb; e += blockDim.x) {
-          const int cc = e / nr, rr = e - cc * nr;
-          if (rr >= cc) pan[cc * ldp + rr] = L[(int64_t)(J + cc) * ldl + J + rr];
-        }
-        __syncthreads();
-        for (int cc = wv; cc < jb; cc += nw) {
-          double a = 0.0;
-          for (int rr = jb + lane; rr < nr; rr += kWave) a = fma(pan[cc * ldp + rr], yv[J + rr], a);
-          a = wave_sum(a);
-          if (lane == 0) dsum[cc] = a;
-        }
-        __syncthreads();
-        if (wv == 0) {  // lane c carries v_c = y_c - (solved part); solutions appear from the last row up
-          double v = lane < jb ? yv[J + lane] - dsum[lane] : 0.0;
-          for (int cc = jb - 1; cc >= 0; --cc) {
-            const double wc = __shfl(v, cc, kWave) / pan[cc * ldp + cc];
-            if (lane == cc)
-              v = wc;
-            else if (lane < cc)
-              v = fma(-pan[lane * ldp + cc], wc, v);
-          }
-          if (lane < jb) yv[J + lane] = v;
-        }
-        __syncthreads();
-        jend = J;
-      }
-    }
-    PH_QO_MARK(5)
-    nb += 1;
+    __syncthreads();
     // ---- reconstruction A^T w (QOPeriods.py:795) and the new residual
     double rs = 0.0;
     for (int n = tid; n < N; n += blockDim.x) {
       double rec = 0.0;
       for (int b = 0; b < nb; ++b) {
         const int i = n % bper[b];
-        if (i < bkeep[b]) rec += yv[boff[b] + i];
+        if (i < bkeep[b]) rec += xv[boff[b] + b + i];
       }
       rs += rec * rec;
       work[n] = (T)((double)data[n] - rec);
     }
-    for (int r = tid; r < K; r += blockDim.x) wts[r] = yv[r];
+    if (LW) zero_pad(work, N);
     recon_sq = block_sum(rs, red);
     __syncthreads();
-    PH_QO_MARK(6)
+    PH_QO_MARK(3)
+    if (singular) break;
   }
   __syncthreads();
 #ifdef PH_QO_TIMERS
   if (w < 12 && tid == 0)
-    printf("qo timers (100 MHz ticks) sweep %lld gram %lld rhs %lld mirror %lld chol(rest) %lld backsub %lld recon %lld | copy %lld panel-load %lld diag %lld rowsolve %lld store %lld trailing %lld  K=%d nb=%d\n",
-           tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[8], tq[9], tq[10], tq[11], tq[12], tq[13], boff[nb], nb);
+    printf("qo timers (100 MHz ticks) sweep %lld rhs %lld cg %lld recon %lld  cg iterations %d K=%d nb=%d\n", tq[0], tq[1], tq[2],
+           tq[3], cg_iters, boff[nb], nb);
 #endif
   // outputs.  When the loop stopped on the test function the reference reports all periods
   // but the last one, yet keeps the weights / dictionary of all of them (QOPeriods.py:584-592).
