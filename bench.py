@@ -370,7 +370,7 @@ def main():
         else:
             wg_sweeps = int(sw.sum())
         lds_bytes = wg_sweeps * n_pass * N_SAMPLES * lds_elem  # what the fold passes read from LDS
-        traffic, tsrc, t_ms = load_recorded_traffic("k_mbest_step1")
+        traffic, tsrc, t_ms = load_recorded_traffic("k_mbest_step1_pair" if win_per_wg == 2 else "k_mbest_step1")
         sec = k1_ms * 1e-3
         line = {
             "metric": METRIC,

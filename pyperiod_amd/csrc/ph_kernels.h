@@ -487,8 +487,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     if (tid == 0) ctl[0] = ctl[1] = 0;  // (read as `ncand` before the last barrier of the previous round)
     // ---- 1. screen of both windows (Periods.py:501-515 in float); values into the idle staging buffer
     f2* vals = reinterpret_cast<f2*>(stg);
-    pair_sweep_plan(pw, N, geomf, plan, wv, n_pass, nw, lane, [&](f2 ss, int q) {
-      if ((lane & 7) == 0) vals[q - p_lo] = ss;
+    pair_sweep_plan(pw, N, geomf, plan, wv, n_pass, nw, [&](f2 ss, int q) {
+      if (pair_lane() == 0) vals[q - p_lo] = ss;
     });
     __syncthreads();
     PH_PAIR_MARK(0)

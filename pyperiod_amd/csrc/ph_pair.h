@@ -44,35 +44,13 @@ __device__ __forceinline__ f2 dpp_f2(f2 v) {
   return f2_make(__int_as_float(a), __int_as_float(b));
 }
 
-// One butterfly level on pairs; see butterfly_merge (ph_device.h) -- the two floats of a pair take the place of
-// the two dwords of a double, so the data movement is instruction for instruction the same.
-__device__ __forceinline__ f2 pair_merge(f2 lo, f2 hi, int mask, int lane) {
-  if (mask == 32 || mask == 16) {
-    unsigned l0 = (unsigned)__float_as_int(lo.x), l1 = (unsigned)__float_as_int(lo.y);
-    unsigned h0 = (unsigned)__float_as_int(hi.x), h1 = (unsigned)__float_as_int(hi.y);
-    if (mask == 32) {
-      const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
-      const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
-      l0 = r0[0]; h0 = r0[1]; l1 = r1[0]; h1 = r1[1];
-    } else {
-      const auto r0 = __builtin_amdgcn_permlane16_swap(l0, h0, false, false);
-      const auto r1 = __builtin_amdgcn_permlane16_swap(l1, h1, false, false);
-      l0 = r0[0]; h0 = r0[1]; l1 = r1[0]; h1 = r1[1];
-    }
-    return f2_make(__int_as_float((int)l0), __int_as_float((int)l1)) +
-           f2_make(__int_as_float((int)h0), __int_as_float((int)h1));
-  }
-  const bool up = lane & mask;  // mask == 8
-  const f2 keep = up ? hi : lo;
-  const f2 send = up ? lo : hi;
-  return keep + dpp_f2<kDppRor8>(send);
-}
-
-__device__ __forceinline__ f2 pair_reduce8(f2 v) {
-  v = v + dpp_f2<kDppHalfMirror>(v);
-  v = v + dpp_f2<kDppXor1>(v);
-  v = v + dpp_f2<kDppXor2>(v);
-  return v;
+// Lane index, recomputed where it is needed (two VALU) instead of kept live across the folds: as a long-lived
+// value it was spilled, and every segment of every pass started with a scratch reload in front of its first LDS
+// address.  The volatile asm keeps the compiler from hoisting it back into one register.
+__device__ __forceinline__ int pair_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
 
 // ---------------------------------------------------------------- few-row single passes (R <= 6)
@@ -181,7 +159,7 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
 // base period p >= 64; same segment logic as wave_pass_seg.
 template <int M>
 __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, const PGeomF* __restrict__ geom,
-                                              int lane, f2 (&total)[3]) {
+                                              f2 (&total)[3]) {
   constexpr int U = (M == 1) ? 2 : M;
   constexpr int CM = (M == 4) ? 2 : 4;
   const int rows = geom[p].rows, cut = geom[p].nfull;
@@ -207,6 +185,7 @@ __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, 
     for (int u = 0; u < 2; ++u) wgt[1 + u] = (start + u * p < qn[1]) ? qf[1] : qs[1];
 #pragma unroll
     for (int u = 0; u < 4; ++u) wgt[3 + u] = (start + u * p < qn[2]) ? qf[2] : qs[2];
+    const int lane = pair_lane();
     const pair_ptr base = (pair_ptr)xs + start + lane;
     const int nchunks = (len + 63) >> 6;
     int c0 = 0;
@@ -254,7 +233,8 @@ __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, 
 }
 
 // p < 64: row-split path of wave_fold_small / wave_partial_small for pairs.
-__device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int N, int p, const PGeomF& g, int lane) {
+__device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int N, int p, const PGeomF& g) {
+  const int lane = pair_lane();
   const int G = 64 / p;
   const int L = G * p;
   const int full = N / L;
@@ -290,72 +270,58 @@ __device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int 
   return (lane < p) ? tot * tot * w : f2_zero();
 }
 
-// The online 8-period butterfly (Butterfly8) on pairs.
-struct PairButterfly8 {
-  f2 l1, l2, l3;
-  int k, myp;
-  __device__ __forceinline__ void reset() {
-    k = 0;
-    myp = 0;
-    l1 = l2 = l3 = f2_zero();
+// All-reduce of a pair over the wavefront (same data movement as wave_allreduce, the two floats in place of the two
+// dwords of a double).
+__device__ __forceinline__ f2 pair_wave_sum(f2 v) {
+  {
+    unsigned a0 = (unsigned)__float_as_int(v.x), a1 = (unsigned)__float_as_int(v.y), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    v = f2_make(__int_as_float((int)r0[0]), __int_as_float((int)r1[0])) + f2_make(__int_as_float((int)r0[1]), __int_as_float((int)r1[1]));
   }
-  template <typename F>
-  __device__ __forceinline__ void push(f2 a, int p, int lane, F&& consume) {
-    if (butterfly8_slot(lane) == k) myp = p;
-    if ((k & 1) == 0) {
-      l1 = a;
-    } else {
-      a = pair_merge(l1, a, 32, lane);
-      if ((k & 2) == 0) {
-        l2 = a;
-      } else {
-        a = pair_merge(l2, a, 16, lane);
-        if ((k & 4) == 0) {
-          l3 = a;
-        } else {
-          const f2 tot = pair_reduce8(pair_merge(l3, a, 8, lane));
-          if (myp != 0) consume(tot, myp);
-          myp = 0;
-        }
-      }
-    }
-    k = (k + 1) & 7;
+  {
+    unsigned a0 = (unsigned)__float_as_int(v.x), a1 = (unsigned)__float_as_int(v.y), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    v = f2_make(__int_as_float((int)r0[0]), __int_as_float((int)r1[0])) + f2_make(__int_as_float((int)r0[1]), __int_as_float((int)r1[1]));
   }
-  template <typename F>
-  __device__ __forceinline__ void flush(int lane, F&& consume) {
-    while (k != 0) push(f2_zero(), 0, lane, consume);
-  }
-};
+  v = v + dpp_f2<kDppRor8>(v);
+  v = v + f2_make(__int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.x), 0x101F)),
+                  __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.y), 0x101F)));
+  v = v + dpp_f2<kDppXor2>(v);
+  v = v + dpp_f2<kDppXor1>(v);
+  return v;
+}
 
-// Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in the 8 lanes that own period q.
+// Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals.
+// Every period is reduced over the wavefront on its own (pair_wave_sum): a few more VALU per period than the online
+// 8-period butterfly of the fp64 sweeps, but nothing is live across the folds -- the butterfly's pending partials
+// were spilled and reloaded in every pass (3.03 -> 2.82 ms for k_mbest_step1_pair at config 2).
 template <typename F>
 __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N, const PGeomF* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end, int stride,
-                                                int lane, F&& consume) {
-  PairButterfly8 bf;
-  bf.reset();
+                                                F&& consume) {
   for (int i = i_first; i < i_end; i += stride) {
     const int p = plan[i].p, m = plan[i].m;
     if (m == 0) {
-      bf.push(pair_partial_small(xs, N, p, geom[p], lane), p, lane, consume);
+      consume(pair_wave_sum(pair_partial_small(xs, N, p, geom[p])), p);
     } else if (m == 1) {
       f2 part[3];
-      pair_pass_seg<1>(xs, p, geom, lane, part);
-      bf.push(part[0], p, lane, consume);
+      pair_pass_seg<1>(xs, p, geom, part);
+      consume(pair_wave_sum(part[0]), p);
     } else if (m == 2) {
       f2 part[3];
-      pair_pass_seg<2>(xs, p, geom, lane, part);
-      bf.push(part[0], p, lane, consume);
-      bf.push(part[1], 2 * p, lane, consume);
+      pair_pass_seg<2>(xs, p, geom, part);
+      consume(pair_wave_sum(part[0]), p);
+      consume(pair_wave_sum(part[1]), 2 * p);
     } else {
       f2 part[3];
-      pair_pass_seg<4>(xs, p, geom, lane, part);
-      bf.push(part[0], p, lane, consume);
-      bf.push(part[1], 2 * p, lane, consume);
-      bf.push(part[2], 4 * p, lane, consume);
+      pair_pass_seg<4>(xs, p, geom, part);
+      consume(pair_wave_sum(part[0]), p);
+      consume(pair_wave_sum(part[1]), 2 * p);
+      consume(pair_wave_sum(part[2]), 4 * p);
     }
   }
-  bf.flush(lane, consume);
 }
 
 // Rigorous radius of the screen, in units of the (scaled) sum of squares ssq of the fp64 residual r:
