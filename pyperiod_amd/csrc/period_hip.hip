@@ -72,6 +72,7 @@ struct ph_ctx {
   DevBuf geomf;  // the same table in float (ph::PGeomF), for the window-pair screen
   int geom_n = -1, geom_max_p = -1;
   bool step1_pair = true;  // PH_STEP1_PAIR=0: always the one-window fp64 kernel for m_best step 1
+  bool s2l_pair = true;    // PH_S2L_PAIR=0: always the one-window kernel for small_to_large
   DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
   int twid_len = -1;
   DevBuf bs_tab;  // Bluestein tables of the last (win_size, min(N, win_size)): M twiddles, chirp, FFT of the wrapped chirp
@@ -514,6 +515,7 @@ int ph_create(int device, ph_ctx** out) {
     if (v == 1 || v == 2 || v == 4) c->plan_max_m = v;
   }
   if (const char* e = std::getenv("PH_STEP1_PAIR")) c->step1_pair = std::atoi(e) != 0;
+  if (const char* e = std::getenv("PH_S2L_PAIR")) c->s2l_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_STEP1_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
@@ -894,6 +896,23 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   PH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), c->stream));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
+  // Window-pair screen (k_small_to_large_pair): fp64 windows, plain projection, candidate periods below N.  Its LDS
+  // is the pair window alone; the fp64 residuals live in an HBM workspace.
+  const size_t lds_pair = carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(ph::kS2LBatch, 8) +
+                          carve_bytes(8, 8) + carve_bytes(8, 4);
+  const bool pair = c->s2l_pair && dtype == PH_F64 && !general && !gwin && n_periods < N &&
+                    lds_pair <= (size_t)c->lds_limit;
+  if (pair) {
+    const size_t gstride = ph::win_stride((size_t)N);
+    PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));
+    auto kernel = ph::k_small_to_large_pair;
+    PH_TRY(allow_lds(kernel, lds_pair));
+    ProfScope ps_(c, "k_small_to_large");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((W + 1) / 2)), dim3(c->sweep_block), lds_pair, c->stream, (const double*)dx,
+                       (int)W, N, thresh, n_periods, static_cast<const ph::PGeomF*>(c->geomf.p),
+                       static_cast<double*>(c->buf[B_GWIN].p), cap, (int*)dcnt, (int*)dper, (double*)dpow, (double*)dbases,
+                       (int*)dstat, dmax);
+  } else
   PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
     using T = decltype(t);
     auto kernel = ph::k_small_to_large<T, decltype(lw)::value>;

@@ -420,9 +420,20 @@ __device__ __forceinline__ int butterfly8_slot(int lane) {
 // Visit ||P_p x||^2 (or max_s |S_p[s]| when MAXABS) for p = p_first, p_first + stride, ...
 // <= p_hi.  consume(value, p) runs in the 8 lanes that own period p.  p_first and stride
 // must be wave-uniform.
-template <typename T, bool MAXABS, bool LDS, typename F>
+// DIRECT: every period is reduced over the wavefront on its own instead of through the 8-period butterfly -- dearer
+// per period (an fp64 all-reduce is 12 cross-lane moves), but nothing is pending across the folds; it pays where a
+// wavefront visits only a few periods between two barriers (k_small_to_large: 8.70 -> 8.19 ms per config-4 shard) and
+// costs 10-25 % in the long sweeps.
+template <typename T, bool MAXABS, bool LDS, bool DIRECT = false, typename F>
 __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
                                            int p_first, int p_hi, int stride, int lane, F&& consume) {
+  if (DIRECT) {  // no state across periods: a full wave reduction per period (consume runs in every lane)
+    for (int p = p_first; p <= p_hi; p += stride) {
+      const double a = wave_partial<T, MAXABS, LDS>(xs, N, p, geom[p], lane);
+      consume(MAXABS ? wave_max(a) : wave_sum(a), p);
+    }
+    return;
+  }
   for (int pb = p_first; pb <= p_hi; pb += 8 * stride) {
     double l1 = 0.0, l2 = 0.0, l3 = 0.0, tot = 0.0;
     for (int k = 0; k < 8; ++k) {

@@ -1109,8 +1109,8 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       // on its cancellation error, reaches the threshold is evaluated exactly below; results
       // screened beyond an accepted period are discarded and recomputed.
       const int hi = min(n_periods, p + kS2LBatch - 1);
-      wave_sweep<T, false, LW>(work, N, geom, p + wv, hi, nw, lane, [&](double ss, int q) {
-        if ((lane & 7) == 0) psq[q - p] = ss;
+      wave_sweep<T, false, LW, true>(work, N, geom, p + wv, hi, nw, lane, [&](double ss, int q) {
+        if (lane == 0) psq[q - p] = ss;
       });
       __syncthreads();
       if (wv == 0) {  // one lane per screened period; the first flagged one is the candidate
@@ -1211,6 +1211,215 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     counts[w] = count;
     status_out[w] = count > cap ? 3 : 0;
     if (count > cap) atomicMax(max_count, count);  // rare: the host retries with this capacity
+  }
+}
+
+// ======================================================================================
+// Periods.small_to_large, window-pair screen (plain projection, fp64 windows).
+//   Two windows per workgroup share the pair window of ph_pair.h: the ascending screen of k_small_to_large
+//   (||r||^2 - ||P_q r||^2 as an estimate of the reference's norm drop, Periods.py:274-281) runs on the float
+//   images of both -- one pass of the wave-per-period fold per candidate period for the two windows.  The fp64
+//   residuals live in an HBM workspace (the input itself until a window accepts its first period); a period whose
+//   estimate, widened by the rigorous float radius (pair_radius) and the fp64 terms of k_small_to_large's bound,
+//   reaches the threshold is evaluated exactly from there (row-order means, direct sum of squares of the trial
+//   residual), so accept decisions, powers and bases are those of the one-window kernel.
+//   The two windows walk the period range together: a batch starts at the smaller of their positions, and a
+//   window ignores screen values below its own position (it re-screens what its partner still has to decide).
+//   LDS: 35 KB per pair at N = 4096 -> four workgroups of eight wavefronts per CU, i.e. eight windows per CU.
+// ======================================================================================
+template <typename T>
+__device__ __forceinline__ void s2l_pair_rescale(float* __restrict__ pwf, int w, int N, float up) {
+  for (int n = threadIdx.x; n < N; n += blockDim.x) pwf[2 * n + w] *= up;
+}
+
+__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large_pair(
+    const double* __restrict__ x, int W, int N, double thresh, int n_periods, const PGeomF* __restrict__ geomf,
+    double* __restrict__ gres, int cap, int* __restrict__ counts, int* __restrict__ periods_out,
+    double* __restrict__ powers_out, double* __restrict__ bases_out, int* __restrict__ status_out,
+    int* __restrict__ max_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  f2* pw = cv.take<f2>(N + kPad);
+  double* red = cv.take<double>(kRedDoubles);
+  f2* psq = cv.take<f2>(kS2LBatch);
+  // per window w: st[w] ||residual||^2, st[2+w] periodic_norm(residual), st[4+w] periodic_norm(data), st[6+w] scale of
+  // the float image; ct[w] next period to decide, ct[2+w] periods accepted, ct[4+w] candidate of this round,
+  // ct[6+w] 1 once a period was accepted (the residual then lives in the workspace)
+  double* st = cv.take<double>(8);
+  int* ct = cv.take<int>(8);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const size_t gstride = win_stride((size_t)N);
+  float* pwf = reinterpret_cast<float*>(pw);
+  const double sqrtN = uniform_f64(sqrt((double)N));
+  for (int i = tid; i < kPad; i += blockDim.x) pw[N + i] = f2_zero();
+  for (int w = 0; w < 2; ++w) {
+    const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+    const bool exists = gw < W;
+    const double* src = x + gw * (int64_t)N;
+    double acc = 0.0;
+    if (exists)
+      for (int n = tid; n < N; n += blockDim.x) {
+        const double v = src[n];
+        acc = fma(v, v, acc);
+      }
+    const double rsq = block_sum(acc, red);
+    const double sc = uniform_f64(pair_pick_scale(rsq, N));
+    for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] = exists ? (float)(src[n] * sc) : 0.0f;
+    if (tid == 0) {
+      st[w] = rsq;
+      st[2 + w] = st[4 + w] = sqrt(rsq) / sqrtN;  // data_norm, Periods.py:269
+      st[6 + w] = sc;
+      ct[w] = exists ? 2 : n_periods + 1;
+      ct[2 + w] = 0;
+      ct[6 + w] = 0;
+    }
+  }
+  __syncthreads();
+#ifdef PH_S2L_TIMERS
+  long long tp[4] = {0, 0, 0, 0};
+  long long tp0 = wall_clock64();
+  int nev = 0, nrounds = 0;
+#define PH_S2LP_MARK(k)                    \
+  {                                        \
+    const long long now_ = wall_clock64(); \
+    tp[k] += now_ - tp0;                   \
+    tp0 = now_;                            \
+  }
+#else
+#define PH_S2LP_MARK(k)
+#endif
+
+  for (;;) {
+    const int p = min(ct[0], ct[1]);
+    if (p > n_periods) break;
+    const int hi = min(n_periods, p + kS2LBatch - 1);
+    // ---- screen [p, hi] on the float images of both windows
+    for (int q = p + wv; q <= hi; q += nw) {
+      f2 part[3];
+      f2 v;
+      if (q >= 64) {
+        pair_pass_seg<1>(pw, q, geomf, part);
+        v = pair_wave_sum(part[0]);
+      } else {
+        v = pair_wave_sum(pair_partial_small(pw, N, q, geomf[q]));
+      }
+      if (pair_lane() == 0) psq[q - p] = v;
+    }
+    __syncthreads();
+    if (wv == 0) {  // one lane per screened period; the first flagged one of each window is its candidate
+      const int q = p + lane;
+      const f2 v = q <= hi ? psq[lane] : f2_zero();
+      for (int w = 0; w < 2; ++w) {
+        bool flag = false;
+        if (q <= hi && q >= ct[w]) {
+          // decision bound of k_small_to_large with the float radius in place of the fp64 one: the screen has
+          // t_s = rsq - psq, the decision is taken on t_e = fl(sum (r - m)^2); |t_s - t_e| <= D = kappa rsq
+          const double rsq = st[w], rn = st[2 + w], dn = st[4 + w], sc = st[6 + w];
+          const double ps = (double)(w ? v.y : v.x) / (sc * sc);
+          const double tsq = fmax(rsq - ps, 0.0);
+          const double est = (rn - sqrt(tsq) / sqrtN) / dn;
+          const double kappa = pair_radius(geomf[q].rows, q) * (1.0 + 1e-9) + ((double)N / 256.0 + 32.0) * 2.220446049250313e-16;
+          const double D = kappa * rsq;
+          const double dsq = fmin(D / fmax(sqrt(tsq), 1e-300), sqrt(D));
+          const double err = dsq / sqrtN / dn + 1e-13;
+          flag = !(est + err <= thresh);  // NaN -> evaluate
+        }
+        const unsigned long long mask = __ballot(flag);
+        const int cnd = mask ? p + __ffsll((long long)mask) - 1 : -1;
+        if (lane == 0) {
+          ct[4 + w] = cnd;
+          if (cnd < 0 && ct[w] <= hi) ct[w] = hi + 1;  // nothing to evaluate: this window moves past the batch
+        }
+      }
+    }
+    __syncthreads();
+    PH_S2LP_MARK(0)
+#ifdef PH_S2L_TIMERS
+    nrounds += 1;
+#endif
+    if (ct[4] < 0 && ct[5] < 0) continue;  // the usual round: no candidate, positions already advanced by wave 0
+    // ---- exact evaluation of each window's candidate (Periods.py:274-286) on its fp64 residual
+    for (int w = 0; w < 2; ++w) {
+      const int cand = ct[4 + w];
+      if (cand < 0) continue;  // (no candidate: finished, ahead of this batch, or moved past it by wave 0)
+      __syncthreads();
+      const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+      const bool moved = ct[6 + w] != 0;
+      const double* res = moved ? gres + gw * gstride : x + gw * (int64_t)N;
+      const double rn = st[2 + w], dn = st[4 + w], sc = st[6 + w];
+      const int count = ct[2 + w];
+      const Fold f(N, cand);
+      double tsq = 0.0;
+      for (int j = tid; j < cand; j += blockDim.x) {
+        const double m = residue_mean(res, f, j, false);
+        const int cnt = f.count(j);
+        for (int r = 0; r < cnt; ++r) {
+          const double t = res[r * cand + j] - m;
+          tsq = fma(t, t, tsq);
+        }
+      }
+      tsq = block_sum(tsq, red);
+      PH_S2LP_MARK(1)
+#ifdef PH_S2L_TIMERS
+      nev += 1;
+#endif
+      const double tn = uniform_f64(sqrt(tsq) / sqrtN);
+      const double imposed = uniform_f64((rn - tn) / dn);
+      if (imposed > thresh) {  // strict, Periods.py:281
+        double* brow = (bases_out && count < cap) ? bases_out + (gw * cap + count) * (int64_t)N : nullptr;
+        double* dst = gres + gw * gstride;
+        for (int j = tid; j < cand; j += blockDim.x) {
+          const double m = residue_mean(res, f, j, false);
+          const int cnt = f.count(j);
+          for (int r = 0; r < cnt; ++r) {
+            const int n = r * cand + j;
+            const double v = res[n] - m;
+            if (brow) brow[n] = m;
+            dst[n] = v;
+            pwf[2 * n + w] = (float)(v * sc);
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (pair_usable(tsq) && tsq * sc * sc < 9.0e-13 * (double)N) {  // float image below 2^-20 RMS: renew its scale
+          const double sc2 = uniform_f64(pair_pick_scale(tsq, N));
+          s2l_pair_rescale<double>(pwf, w, N, (float)(sc2 / sc));
+          if (tid == 0) st[6 + w] = sc2;
+        }
+        if (tid == 0) {
+          if (count < cap) {
+            periods_out[gw * cap + count] = cand;
+            powers_out[gw * cap + count] = imposed;
+          }
+          ct[2 + w] = count + 1;
+          ct[6 + w] = 1;
+          st[w] = tsq;
+          st[2 + w] = tn;
+        }
+      }
+      if (tid == 0) ct[w] = cand + 1;
+      PH_S2LP_MARK(2)
+    }
+    __syncthreads();
+  }
+#ifdef PH_S2L_TIMERS
+  if (blockIdx.x < 6 && tid == 0)
+    printf("s2l pair timers (100 MHz ticks) screen %lld exact %lld update %lld  rounds %d events %d accepts %d %d\n", tp[0], tp[1],
+           tp[2], nrounds, nev, ct[2], ct[3]);
+#endif
+  __syncthreads();
+  if (tid < 2) {
+    const int64_t gw = 2 * (int64_t)blockIdx.x + tid;
+    if (gw < W) {
+      const int count = ct[2 + tid];
+      counts[gw] = count;
+      status_out[gw] = count > cap ? 3 : 0;
+      if (count > cap) atomicMax(max_count, count);  // rare: the host retries with this capacity
+    }
   }
 }
 

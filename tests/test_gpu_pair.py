@@ -166,3 +166,48 @@ def test_residual_collapse_renews_the_float_scale(engines):
     assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[3], b[3])
     want = po.m_best(xb[1], 3)
     assert np.array_equal(b[0][1], want[0]) and rel_err(b[2][1], want[2]) < TOL
+
+
+def test_small_to_large_pair_kernel_equals_one_window_kernel():
+    """The window-pair screen of small_to_large (k_small_to_large_pair) against the one-window kernel (PH_S2L_PAIR=0):
+    counts, periods, powers and bases bit for bit -- odd batches (a lone window in the last pair), thresholds that
+    accept many and few periods, a threshold planted 1e-12 either side of an accepted period's drop."""
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import PeriodEngine
+
+    old = os.environ.get("PH_S2L_PAIR")
+    os.environ["PH_S2L_PAIR"] = "0"
+    single = PeriodEngine(0)
+    os.environ["PH_S2L_PAIR"] = "1"
+    pair = PeriodEngine(0)
+    if old is None:
+        del os.environ["PH_S2L_PAIR"]
+    else:
+        os.environ["PH_S2L_PAIR"] = old
+    try:
+        for n, w, thresh, n_periods in ((4096, 9, 0.05, None), (2000, 5, 0.1, None), (1000, 3, 0.02, 400), (97, 1, 0.01, None),
+                                        (6000, 2, 0.03, None)):
+            x = multi_sinusoid_batch(300 + n, w, n)
+            a = single.small_to_large(x, thresh, n_periods, cap=64)
+            b = pair.small_to_large(x, thresh, n_periods, cap=64)
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v), (n, thresh)
+            want = po.small_to_large(x[0], thresh, n_periods)
+            k = int(b[0][0])
+            assert list(b[1][0][:k]) == list(want[0]) and rel_err(b[2][0][:k], np.array(want[1])) < TOL
+        # knife edge: the threshold within 1e-12 of the drop of an accepted period, both sides
+        x = multi_sinusoid_batch(77, 2, 4096)
+        ref = pair.small_to_large(x, 0.05, None, cap=64)
+        drop = float(ref[2][0][2])  # third accepted period of window 0
+        for t in (drop * (1 - 1e-12), drop * (1 + 1e-12)):
+            a = single.small_to_large(x, t, None, cap=64)
+            b = pair.small_to_large(x, t, None, cap=64)
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v)
+            want = po.small_to_large(x[0], t)
+            assert list(b[1][0][: int(b[0][0])]) == list(want[0])
+    finally:
+        single.close()
+        pair.close()
