@@ -449,7 +449,7 @@ size_t pair_lds_bytes(int N, int num, int P) {
   return 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * num, 8) + carve_bytes(2 * num, 4) +
          carve_bytes(2 * ((P + 31) / 32), 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(16, 4) +
-         carve_bytes(4, 8);
+         carve_bytes(4, 8) + carve_bytes(ph::kPairSmallP, 8);
 }
 
 // The window-pair screen serves fp64 windows, plain projection, candidate periods below N, when the pair window

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
 // ======================================================================================
 constexpr int kPairListCap = 96;
 constexpr int kPairCoop = 6;  // up to this many survivors are evaluated by the whole workgroup, one after the other
+constexpr int kPairSmallP = 256;  // winners up to this period: means through LDS, subtraction by all threads
 
 __device__ __forceinline__ bool pair_usable(double rsq) { return rsq > 0.0 && rsq < 1.79e308; }
 
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   // [6+w] status, [8+w] sweeps done, [10+w] still running, [12+w] every period exactly
   int* ctl = cv.take<int>(16);
   double* dst2 = cv.take<double>(4);  // [w] sum of squares of the scaled residual (unit of the radius), [2+w] its scale
+  double* msm = cv.take<double>(kPairSmallP);  // means of a short winning period
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -679,20 +681,46 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
           double* dst = gres + gw * gstride;
           double acc = 0.0;
           const Fold f(N, bestp);
-          for (int j = tid; j < bestp; j += blockDim.x) {
-            const double m = residue_mean(stg, f, j, false);
-            const int cnt = f.count(j);
-            if (action == 1)
-              brow[j] = m;
-            else if (action == 2)
-              brow[j] += m;
+          if (bestp <= kPairSmallP) {
+            // a short period (the usual winner of m_best_gamma): its few residues have hundreds of rows each -- the
+            // row-order means stay with one thread per residue, the subtraction is spread over the workgroup
+            for (int j = tid; j < bestp; j += blockDim.x) {
+              const double m = residue_mean(stg, f, j, false);
+              msm[j] = m;
+              if (action == 1)
+                brow[j] = m;
+              else if (action == 2)
+                brow[j] += m;
+            }
+            __syncthreads();
             if (more) {
-              for (int r = 0; r < cnt; ++r) {
-                const int n = r * bestp + j;
-                const double v = stg[n] - m;
+              int idx = tid % bestp;
+              const int step = blockDim.x % bestp;
+              for (int n = tid; n < N; n += blockDim.x) {
+                const double v = stg[n] - msm[idx];
                 dst[n] = v;
                 pwf[2 * n + w] = (float)(v * sc);
                 acc = fma(v, v, acc);
+                idx += step;
+                idx = idx >= bestp ? idx - bestp : idx;
+              }
+            }
+          } else {
+            for (int j = tid; j < bestp; j += blockDim.x) {
+              const double m = residue_mean(stg, f, j, false);
+              const int cnt = f.count(j);
+              if (action == 1)
+                brow[j] = m;
+              else if (action == 2)
+                brow[j] += m;
+              if (more) {
+                for (int r = 0; r < cnt; ++r) {
+                  const int n = r * bestp + j;
+                  const double v = stg[n] - m;
+                  dst[n] = v;
+                  pwf[2 * n + w] = (float)(v * sc);
+                  acc = fma(v, v, acc);
+                }
               }
             }
           }

@@ -270,27 +270,39 @@ __device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int 
   return (lane < p) ? tot * tot * w : f2_zero();
 }
 
-// All-reduce of a pair over the wavefront (same data movement as wave_allreduce, the two floats in place of the two
-// dwords of a double).
+// All-reduce of a pair over the wavefront.  Inside a row of 16 lanes the DPP operand folds into the add
+// (v_add_f32_dpp: one instruction per float and level; ror 8, half mirror, xor 2, xor 1 -- no ds_swizzle, nothing goes
+// through the LDS pipe), then odd / even rows and half-waves are exchanged with v_permlane16_swap / v_permlane32_swap.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ f2 pair_wave_sum(f2 v) {
+  float x = v.x, y = v.y;
+  x += dpp_f32<kDppRor8>(x);
+  y += dpp_f32<kDppRor8>(y);
+  x += dpp_f32<kDppHalfMirror>(x);
+  y += dpp_f32<kDppHalfMirror>(y);
+  x += dpp_f32<kDppXor2>(x);
+  y += dpp_f32<kDppXor2>(y);
+  x += dpp_f32<kDppXor1>(x);
+  y += dpp_f32<kDppXor1>(y);
   {
-    unsigned a0 = (unsigned)__float_as_int(v.x), a1 = (unsigned)__float_as_int(v.y), b0 = a0, b1 = a1;
-    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-    v = f2_make(__int_as_float((int)r0[0]), __int_as_float((int)r1[0])) + f2_make(__int_as_float((int)r0[1]), __int_as_float((int)r1[1]));
-  }
-  {
-    unsigned a0 = (unsigned)__float_as_int(v.x), a1 = (unsigned)__float_as_int(v.y), b0 = a0, b1 = a1;
+    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
     const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
     const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-    v = f2_make(__int_as_float((int)r0[0]), __int_as_float((int)r1[0])) + f2_make(__int_as_float((int)r0[1]), __int_as_float((int)r1[1]));
+    x = __int_as_float((int)r0[0]) + __int_as_float((int)r0[1]);
+    y = __int_as_float((int)r1[0]) + __int_as_float((int)r1[1]);
   }
-  v = v + dpp_f2<kDppRor8>(v);
-  v = v + f2_make(__int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.x), 0x101F)),
-                  __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.y), 0x101F)));
-  v = v + dpp_f2<kDppXor2>(v);
-  v = v + dpp_f2<kDppXor1>(v);
-  return v;
+  {
+    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    x = __int_as_float((int)r0[0]) + __int_as_float((int)r0[1]);
+    y = __int_as_float((int)r1[0]) + __int_as_float((int)r1[1]);
+  }
+  return f2_make(x, y);
 }
 
 // Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals.

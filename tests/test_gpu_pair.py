@@ -186,14 +186,18 @@ def test_small_to_large_pair_kernel_equals_one_window_kernel():
         del os.environ["PH_S2L_PAIR"]
     else:
         os.environ["PH_S2L_PAIR"] = old
+    def same(a, b):  # counts, periods, powers, bases (the rows the kernels wrote), status
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+        for w, k in enumerate(a[0]):
+            assert np.array_equal(a[3][w, :k], b[3][w, :k])
+
     try:
         for n, w, thresh, n_periods in ((4096, 9, 0.05, None), (2000, 5, 0.1, None), (1000, 3, 0.02, 400), (97, 1, 0.01, None),
                                         (6000, 2, 0.03, None)):
             x = multi_sinusoid_batch(300 + n, w, n)
             a = single.small_to_large(x, thresh, n_periods, cap=64)
             b = pair.small_to_large(x, thresh, n_periods, cap=64)
-            for u, v in zip(a, b):
-                assert np.array_equal(u, v), (n, thresh)
+            same(a, b)
             want = po.small_to_large(x[0], thresh, n_periods)
             k = int(b[0][0])
             assert list(b[1][0][:k]) == list(want[0]) and rel_err(b[2][0][:k], np.array(want[1])) < TOL
@@ -204,8 +208,7 @@ def test_small_to_large_pair_kernel_equals_one_window_kernel():
         for t in (drop * (1 - 1e-12), drop * (1 + 1e-12)):
             a = single.small_to_large(x, t, None, cap=64)
             b = pair.small_to_large(x, t, None, cap=64)
-            for u, v in zip(a, b):
-                assert np.array_equal(u, v)
+            same(a, b)
             want = po.small_to_large(x[0], t)
             assert list(b[1][0][: int(b[0][0])]) == list(want[0])
     finally:

@@ -3,15 +3,16 @@
 import collections, csv, glob, json, sys
 cases = json.load(open(sys.argv[1]))
 W = cases["windows"]
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "k_sweep"
 disp = collections.OrderedDict()
 for f in glob.glob(f"{sys.argv[2]}/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_sweep" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             disp.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 dur = []
 if len(sys.argv) > 3:
     for f in glob.glob(f"{sys.argv[3]}/**/*_kernel_trace.csv", recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "k_sweep" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 ids = sorted(disp)
