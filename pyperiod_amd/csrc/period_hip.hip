@@ -73,6 +73,7 @@ struct ph_ctx {
   int geom_n = -1, geom_max_p = -1;
   bool step1_pair = true;  // PH_STEP1_PAIR=0: always the one-window fp64 kernel for m_best step 1
   bool s2l_pair = true;    // PH_S2L_PAIR=0: always the one-window kernel for small_to_large
+  bool bc_pair = true;     // PH_BC_PAIR=0: always the one-window kernel for best_correlation
   DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
   int twid_len = -1;
   DevBuf bs_tab;  // Bluestein tables of the last (win_size, min(N, win_size)): M twiddles, chirp, FFT of the wrapped chirp
@@ -516,6 +517,7 @@ int ph_create(int device, ph_ctx** out) {
   }
   if (const char* e = std::getenv("PH_STEP1_PAIR")) c->step1_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_S2L_PAIR")) c->s2l_pair = std::atoi(e) != 0;
+  if (const char* e = std::getenv("PH_BC_PAIR")) c->bc_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_STEP1_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
@@ -973,6 +975,22 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
+  // Window-pair screen (k_best_correlation_pair): fp64 windows, plain projection, pair window + staging buffer in LDS
+  const size_t lds_pair = 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+                          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(8, 4) +
+                          carve_bytes(10, 8);
+  const bool pair = c->bc_pair && dtype == PH_F64 && !general && !gwin && max_length <= N && max_length - 1 >= 2 &&
+                    lds_pair <= (size_t)c->lds_limit;
+  if (pair) {
+    const size_t gstride = ph::win_stride((size_t)N);
+    PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));
+    auto kernel = ph::k_best_correlation_pair;
+    PH_TRY(allow_lds(kernel, lds_pair));
+    ProfScope ps_(c, "k_best_correlation");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((W + 1) / 2)), dim3(1024), lds_pair, c->stream, (const double*)dx, (int)W, N,
+                       num, max_length, ratio, geom, static_cast<const ph::PGeomF*>(c->geomf.p), plan, n_pass,
+                       static_cast<double*>(c->buf[B_GWIN].p), (uint32_t*)dper, (double*)dnrm, (double*)dbases, (int*)dstat);
+  } else
   PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
     using T = decltype(t);
     auto kernel = ph::k_best_correlation<T, decltype(lw)::value>;

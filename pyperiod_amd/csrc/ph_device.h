@@ -109,6 +109,27 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return uniform_f64(t);
 }
 
+// sums of two values over the workgroup with one pair of barriers (every thread gets both)
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+  const int tid = threadIdx.x;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((tid & (kWave - 1)) == 0) {
+    red[tid >> 6] = a;
+    red[kMaxWaves + (tid >> 6)] = b;
+  }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+  for (int i = 0; i < nw; ++i) {
+    ta += red[i];
+    tb += red[kMaxWaves + i];
+  }
+  __syncthreads();
+  a = uniform_f64(ta);
+  b = uniform_f64(tb);
+}
+
 // Maximum over the workgroup (every thread gets it; NaN inputs are ignored by fmax, -inf if there is none).
 __device__ __forceinline__ double block_max(double v, double* red) {
   const int tid = threadIdx.x;

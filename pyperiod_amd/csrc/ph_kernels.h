@@ -1632,6 +1632,230 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 }
 
 // ======================================================================================
+// Periods.best_correlation, window-pair screen (plain projection, fp64 windows that fit the LDS twice).
+//   Same layout as k_mbest_step1_pair: two windows per workgroup, pair window + one fp64 staging buffer in LDS, fp64
+//   residuals in the HBM workspace.  Per outer iteration (Periods.py:320-347) the multi-period passes run over the
+//   float images with "largest square" in place of "sum of squares" (max_s |S_p[s]|, :327-331); |sqrt(screen) - max|S||
+//   <= 1.25 (R + 2) 2^-24 sum|r| (any summation order of R float-rounded terms), so the periods whose upper bound
+//   reaches the best lower bound contain the exact argmax; they are re-evaluated with the row-order fp64 pass of
+//   k_best_correlation and compared exactly as there (strict '>', lowest period among equals).  Both windows of a pair
+//   always run the same number of iterations, so they never fall out of step.
+// ======================================================================================
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_best_correlation_pair(
+    const double* __restrict__ x, int W, int N, int num, int max_length, double ratio, const PGeom* __restrict__ geom,
+    const PGeomF* __restrict__ geomf, const PassPlan* __restrict__ plan, int n_pass, double* __restrict__ gres,
+    uint32_t* __restrict__ periods_out, double* __restrict__ norms_out, double* __restrict__ bases_out,
+    int* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Carve cv(smem);
+  f2* pw = cv.take<f2>(N + kPad);
+  double* stg = cv.take<double>(N + kPad);
+  double* red = cv.take<double>(kRedDoubles);
+  double* wbest = cv.take<double>(kMaxWaves);
+  int* wbestp = cv.take<int>(kMaxWaves);
+  int* list = cv.take<int>(2 * kPairListCap);
+  int* ctl = cv.take<int>(8);        // [w] survivors listed, [2+w] status, [4+w] window exists
+  double* st = cv.take<double>(10);  // [w] sum|r| (scaled), [2+w] scale, [4+w] og, [6+w] old_norm, [8+w] usable (1 / 0)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const size_t gstride = win_stride((size_t)N);
+  float* pwf = reinterpret_cast<float*>(pw);
+  const double sqrtN = uniform_f64(sqrt((double)N));
+  const int p_lo = 2, p_hi = max_length - 1, P = p_hi - p_lo + 1;
+
+  zero_pad(stg, N);
+  for (int i = tid; i < kPad; i += blockDim.x) pw[N + i] = f2_zero();
+  for (int w = 0; w < 2; ++w) {
+    const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+    const bool exists = gw < W;
+    __syncthreads();
+    if (exists) {
+      load_window(x + gw * (int64_t)N, stg, N);
+    } else {
+      for (int n = tid; n < N; n += blockDim.x) stg[n] = 0.0;
+    }
+    __syncthreads();
+    double a2 = 0.0, a1 = 0.0;
+    for (int n = tid; n < N; n += blockDim.x) {
+      const double v = stg[n];
+      a2 = fma(v, v, a2);
+      a1 += fabs(v);
+    }
+    block_sum2(a2, a1, red);
+    const double sc = uniform_f64(pair_pick_scale(a2, N));
+    for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] = (float)(stg[n] * sc);
+    if (tid == 0) {
+      st[w] = a1 * sc * (1.0 + 1e-9);
+      st[2 + w] = sc;
+      st[4 + w] = st[6 + w] = sqrt(a2) / sqrtN;  // og, old_norm (Periods.py:316-317)
+      st[8 + w] = pair_usable(a2) ? 1.0 : 0.0;
+      ctl[2 + w] = 0;
+      ctl[4 + w] = exists ? 1 : 0;
+    }
+  }
+  __syncthreads();
+
+  for (int it = 0; it < num; ++it) {
+    const bool run0 = ctl[4] && ctl[2] == 0, run1 = ctl[5] && ctl[3] == 0;
+    __syncthreads();
+    if (tid == 0) ctl[0] = ctl[1] = 0;
+    if ((run0 || run1) && P > 0) {
+      // ---- screen: largest square of a residue sum per period, both windows (Periods.py:324-331 in float)
+      f2* vals = reinterpret_cast<f2*>(stg);
+      pair_sweep_plan<true>(pw, N, geomf, plan, wv, n_pass, nw, [&](f2 v, int q) {
+        if (pair_lane() == 0) vals[q - p_lo] = v;
+      });
+      __syncthreads();
+      const bool scr0 = run0 && st[8] != 0.0, scr1 = run1 && st[9] != 0.0;
+      if (scr0 || scr1) {
+        const double u0 = 1.25 * 5.9604644775390625e-08 * st[0], u1 = 1.25 * 5.9604644775390625e-08 * st[1];
+        const float fn = (float)N;
+        double lo0 = -1.0 / 0.0, lo1 = -1.0 / 0.0;
+        for (int idx = tid; idx < P; idx += blockDim.x) {
+          const f2 v = vals[idx];
+          const double rr = (double)(pair_rows_upper(fn, p_lo + idx) + 2);
+          lo0 = fmax(lo0, sqrt((double)v.x) - rr * u0);
+          lo1 = fmax(lo1, sqrt((double)v.y) - rr * u1);
+        }
+        lo0 = wave_max(lo0);
+        lo1 = wave_max(lo1);
+        if (lane == 0) {
+          red[wv] = lo0;
+          red[kMaxWaves + wv] = lo1;
+        }
+        __syncthreads();
+        lo0 = red[0];
+        lo1 = red[kMaxWaves];
+        for (int i = 1; i < nw; ++i) {
+          lo0 = fmax(lo0, red[i]);
+          lo1 = fmax(lo1, red[kMaxWaves + i]);
+        }
+        for (int idx = tid; idx < P; idx += blockDim.x) {
+          const f2 v = vals[idx];
+          const double rr = (double)(pair_rows_upper(fn, p_lo + idx) + 2);
+          const double h0 = sqrt((double)v.x) + rr * u0, h1 = sqrt((double)v.y) + rr * u1;
+          if (scr0 && h0 > 0.0 && h0 >= lo0) {
+            const int k = atomicAdd(&ctl[0], 1);
+            if (k < kPairListCap) list[k] = p_lo + idx;
+          }
+          if (scr1 && h1 > 0.0 && h1 >= lo1) {
+            const int k = atomicAdd(&ctl[1], 1);
+            if (k < kPairListCap) list[kPairListCap + k] = p_lo + idx;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int w = 0; w < 2; ++w) {
+      const int64_t gw = 2 * (int64_t)blockIdx.x + w;
+      if (!ctl[4 + w]) continue;
+      double* brow = bases_out + (gw * num + it) * (int64_t)N;
+      int status = ctl[2 + w];
+      uint32_t keep_p = 0u;
+      double keep_n = 0.0;
+      bool zero_row = true;
+      const double og = st[4 + w], old_norm = st[6 + w], sc = st[2 + w];
+      const bool exact_all = st[8 + w] == 0.0 || ctl[w] > kPairListCap;
+      const int ncand = exact_all ? P : ctl[w];
+      __syncthreads();
+      if (status == 0) {
+        const double* src = it == 0 ? x + gw * (int64_t)N : gres + gw * gstride;
+        load_window(src, stg, N);
+        __syncthreads();
+        double best = 0.0;
+        int bestp = 0;
+        for (int k = wv; k < ncand; k += nw) {  // row-order sums, bit-identical to the reference's sum(x[s::q])
+          const int q = exact_all ? p_lo + k : list[w * kPairListCap + k];
+          const double v = wave_max(wave_partial<double, true, true>(stg, N, q, geom[q], lane));
+          if (v > best || (v == best && bestp != 0 && q < bestp)) {
+            best = v;
+            bestp = q;
+          }
+        }
+        if (!(best > 0.0)) bestp = 0;
+        if (lane == 0) {
+          wbest[wv] = best;
+          wbestp[wv] = bestp;
+        }
+        __syncthreads();
+        best = 0.0;
+        bestp = 0;
+        for (int k = 0; k < nw; ++k) {
+          const double v = wbest[k];
+          const int pp = wbestp[k];
+          if (pp != 0 && (v > best || (v == best && pp < bestp))) {
+            best = v;
+            bestp = pp;
+          }
+        }
+        __syncthreads();
+        if (bestp == 0) {
+          status = 1;  // reference: project(data, None) raises
+        } else {
+          // project, subtract unconditionally (:334-340); the new residual goes to the workspace and, as floats, into pw
+          double* dst = gres + gw * gstride;
+          double a2 = 0.0, a1 = 0.0;
+          const Fold f(N, bestp);
+          for (int j = tid; j < bestp; j += blockDim.x) {
+            const double m = residue_mean(stg, f, j, false);
+            const int cnt = f.count(j);
+            for (int r = 0; r < cnt; ++r) {
+              const int n = r * bestp + j;
+              const double v = stg[n] - m;
+              brow[n] = m;
+              dst[n] = v;
+              pwf[2 * n + w] = (float)(v * sc);
+              a2 = fma(v, v, a2);
+              a1 += fabs(v);
+            }
+          }
+          block_sum2(a2, a1, red);
+          const double this_norm = sqrt(a2) / sqrtN;
+          const double gain = (old_norm - this_norm) / og;
+          zero_row = !(gain > ratio);  // :343
+          if (!zero_row) {
+            keep_p = (uint32_t)bestp;
+            keep_n = gain;
+          }
+          double sc2 = sc;
+          const bool ok = pair_usable(a2);
+          if (ok && a2 * sc * sc < 9.0e-13 * (double)N) {  // float image below 2^-20 RMS: renew its scale
+            sc2 = uniform_f64(pair_pick_scale(a2, N));
+            const float up = (float)(sc2 / sc);
+            __syncthreads();
+            for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] *= up;
+          }
+          if (tid == 0) {
+            st[w] = a1 * sc2 * (1.0 + 1e-9);
+            st[2 + w] = sc2;
+            if (!zero_row) st[6 + w] = this_norm;
+            st[8 + w] = ok ? 1.0 : 0.0;
+          }
+        }
+      }
+      if (zero_row) {
+        __syncthreads();  // (brow may hold this round's projection)
+        for (int n = tid; n < N; n += blockDim.x) brow[n] = 0.0;
+      }
+      if (tid == 0) {
+        periods_out[gw * num + it] = keep_p;
+        norms_out[gw * num + it] = keep_n;
+        ctl[2 + w] = status;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (tid < 2) {
+    const int64_t gw = 2 * (int64_t)blockIdx.x + tid;
+    if (gw < W) status_out[gw] = ctl[2 + tid];
+  }
+}
+
+// ======================================================================================
 // Periods.best_frequency  (Periods.py:351-398).  Two launches per round:
 //   k_bf_spectrum: grid (bin chunks, W).  The residual is staged in LDS; thread per rfft bin k,
 //     X[k] = sum_n x[n] (cos - i sin)(2 pi k n / L) with the phase index k n mod L kept
@@ -2208,27 +2432,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 // ======================================================================================
 constexpr int kQoMaxBlocks = 64;
 constexpr int kQoPairTab = 16;  // dictionaries of up to this many blocks keep their pair constants in LDS
-
-// sums of two values over the workgroup with one pair of barriers (every thread gets both)
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
-  const int tid = threadIdx.x;
-  const int nw = (blockDim.x + kWave - 1) / kWave;
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if ((tid & (kWave - 1)) == 0) {
-    red[tid >> 6] = a;
-    red[kMaxWaves + (tid >> 6)] = b;
-  }
-  __syncthreads();
-  double ta = 0.0, tb = 0.0;
-  for (int i = 0; i < nw; ++i) {
-    ta += red[i];
-    tb += red[kMaxWaves + i];
-  }
-  __syncthreads();
-  a = uniform_f64(ta);
-  b = uniform_f64(tb);
-}
 
 __device__ __forceinline__ int qo_gcd(int a, int b) {
   while (b != 0) {

@@ -36,6 +36,13 @@ __device__ __forceinline__ f2 f2_make(float a, float b) {
 }
 __device__ __forceinline__ f2 f2_zero() { return f2_make(0.0f, 0.0f); }
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 f2_max(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+// accumulate one residue sum t: sum of squares (norm screens) or largest square (MX: the max |S| screen of
+// best_correlation, Periods.py:327-331)
+template <bool MX>
+__device__ __forceinline__ f2 f2_acc(f2 part, f2 t) {
+  return MX ? f2_max(part, t * t) : f2_fma(t, t, part);
+}
 
 template <int CTRL>
 __device__ __forceinline__ f2 dpp_f2(f2 v) {
@@ -54,7 +61,7 @@ __device__ __forceinline__ int pair_lane() {
 }
 
 // ---------------------------------------------------------------- few-row single passes (R <= 6)
-template <int NR, int C, bool MASK>
+template <int NR, int C, bool MASK, bool MX>
 __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int lane, f2& part) {
   f2 v[NR][C];
 #pragma unroll
@@ -69,29 +76,29 @@ __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid,
 #pragma unroll
     for (int r = 1; r < NR; ++r) t += v[r][c];
     if (MASK) t = (64 * c + lane < nvalid) ? t : f2_zero();
-    part = f2_fma(t, t, part);
+    part = f2_acc<MX>(part, t);
   }
 }
 
-template <int NR>
+template <int NR, bool MX>
 __device__ __forceinline__ void pair_rows_segment(pair_ptr base, int p, int len, int lane, f2& part) {
   constexpr int CG = NR <= 4 ? 4 : 2;
   const int nchunks = (len + 63) >> 6;
   const int whole = len >> 6;
   int c0 = 0;
-  for (; c0 + CG <= whole; c0 += CG) pair_rows_group<NR, CG, false>(base + 64 * c0, p, 64 * CG, lane, part);
+  for (; c0 + CG <= whole; c0 += CG) pair_rows_group<NR, CG, false, MX>(base + 64 * c0, p, 64 * CG, lane, part);
   for (; c0 + 1 < nchunks; c0 += 2) {
     asm volatile("" ::: "memory");
-    pair_rows_group<NR, 2, true>(base + 64 * c0, p, len - 64 * c0, lane, part);
+    pair_rows_group<NR, 2, true, MX>(base + 64 * c0, p, len - 64 * c0, lane, part);
   }
   if (c0 < nchunks) {
     asm volatile("" ::: "memory");
-    pair_rows_group<NR, 1, true>(base + 64 * c0, p, len - 64 * c0, lane, part);
+    pair_rows_group<NR, 1, true, MX>(base + 64 * c0, p, len - 64 * c0, lane, part);
   }
 }
 
 // ---------------------------------------------------------------- general segmented group (see seg_group)
-template <int M, int U, int C, bool MASK>
+template <int M, int U, int C, bool MASK, bool MX>
 __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, int nvalid, int lane,
                                                const float (&wgt)[7], f2 (&part)[3]) {
   static_assert(U % M == 0, "a row block must cover whole class cycles");
@@ -137,8 +144,15 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
       for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : f2_zero();
     }
     if (M == 1) {
-      const f2 t = a[0][c];
-      part[0] = f2_fma(t, t, part[0]);
+      part[0] = f2_acc<MX>(part[0], a[0][c]);
+    } else if (MX) {  // max |S| of p, 2p and (M == 4) 4p from the class sums; no count weights
+      const f2 e = M == 4 ? a[0][c] + a[2 % M][c] : a[0][c], o = M == 4 ? a[1 % M][c] + a[3 % M][c] : a[1 % M][c];
+      part[0] = f2_acc<true>(part[0], e + o);
+      part[1] = f2_acc<true>(f2_acc<true>(part[1], e), o);
+      if (M == 4) {
+#pragma unroll
+        for (int u = 0; u < M; ++u) part[2] = f2_acc<true>(part[2], a[u][c]);
+      }
     } else if (M == 2) {
       const f2 e = a[0][c], o = a[1 % M][c], t = e + o;
       part[0] = f2_fma(t, t, part[0]);
@@ -157,7 +171,7 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
 
 // Per-lane partials of sum_j S_q[j]^2 / cnt_q[j] of BOTH windows for q = p (M >= 1), 2p (M >= 2), 4p (M == 4),
 // base period p >= 64; same segment logic as wave_pass_seg.
-template <int M>
+template <int M, bool MX = false>
 __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, const PGeomF* __restrict__ geom,
                                               f2 (&total)[3]) {
   constexpr int U = (M == 1) ? 2 : M;
@@ -196,34 +210,39 @@ __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, 
     if (M == 1) {
       done = true;
       switch (nrows) {
-        case 1: pair_rows_segment<1>(base, p, len, lane, part[0]); break;
-        case 2: pair_rows_segment<2>(base, p, len, lane, part[0]); break;
-        case 3: pair_rows_segment<3>(base, p, len, lane, part[0]); break;
-        case 4: pair_rows_segment<4>(base, p, len, lane, part[0]); break;
-        case 5: pair_rows_segment<5>(base, p, len, lane, part[0]); break;
-        case 6: pair_rows_segment<6>(base, p, len, lane, part[0]); break;
+        case 1: pair_rows_segment<1, MX>(base, p, len, lane, part[0]); break;
+        case 2: pair_rows_segment<2, MX>(base, p, len, lane, part[0]); break;
+        case 3: pair_rows_segment<3, MX>(base, p, len, lane, part[0]); break;
+        case 4: pair_rows_segment<4, MX>(base, p, len, lane, part[0]); break;
+        case 5: pair_rows_segment<5, MX>(base, p, len, lane, part[0]); break;
+        case 6: pair_rows_segment<6, MX>(base, p, len, lane, part[0]); break;
         default: done = false; break;
       }
     }
     if (done) {
     } else if (CM == 4) {
-      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
+      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false, MX>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
       switch (nchunks - c0) {
-        case 4: pair_seg_group<M, U, 4, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 3: pair_seg_group<M, U, 3, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 2: pair_seg_group<M, U, 2, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: pair_seg_group<M, U, 1, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 4: pair_seg_group<M, U, 4, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 3: pair_seg_group<M, U, 3, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 2: pair_seg_group<M, U, 2, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: pair_seg_group<M, U, 1, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         default: break;
       }
     } else {
-      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
+      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false, MX>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
       switch (nchunks - c0) {
-        case 2: pair_seg_group<M, U, 2, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: pair_seg_group<M, U, 1, true>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 2: pair_seg_group<M, U, 2, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
+        case 1: pair_seg_group<M, U, 1, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
         default: break;
       }
     }
-    if (M == 1) {
+    if (MX) {
+      if (M <= 2) {
+        total[0] = f2_max(total[0], sacc[0]);
+        total[1] = f2_max(total[1], sacc[1]);
+      }
+    } else if (M == 1) {
       total[0] = f2_fma(sacc[0], f2_make(wgt[0], wgt[0]), total[0]);
     } else if (M == 2) {
       total[0] = f2_fma(sacc[0], f2_make(wgt[0], wgt[0]), total[0]);
@@ -233,6 +252,7 @@ __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, 
 }
 
 // p < 64: row-split path of wave_fold_small / wave_partial_small for pairs.
+template <bool MX = false>
 __device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int N, int p, const PGeomF& g) {
   const int lane = pair_lane();
   const int G = 64 / p;
@@ -266,7 +286,7 @@ __device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int 
     const float oy = __shfl(tot.y, src & (kWave - 1), kWave);
     tot += (src < L) ? f2_make(ox, oy) : f2_zero();
   }
-  const float w = (lane < g.nfull) ? g.w_full : g.w_short;
+  const float w = MX ? 1.0f : (lane < g.nfull) ? g.w_full : g.w_short;
   return (lane < p) ? tot * tot * w : f2_zero();
 }
 
@@ -305,33 +325,61 @@ __device__ __forceinline__ f2 pair_wave_sum(f2 v) {
   return f2_make(x, y);
 }
 
+__device__ __forceinline__ f2 pair_wave_max(f2 v) {  // non-negative values (squares)
+  float x = v.x, y = v.y;
+  x = fmaxf(x, dpp_f32<kDppRor8>(x));
+  y = fmaxf(y, dpp_f32<kDppRor8>(y));
+  x = fmaxf(x, dpp_f32<kDppHalfMirror>(x));
+  y = fmaxf(y, dpp_f32<kDppHalfMirror>(y));
+  x = fmaxf(x, dpp_f32<kDppXor2>(x));
+  y = fmaxf(y, dpp_f32<kDppXor2>(y));
+  x = fmaxf(x, dpp_f32<kDppXor1>(x));
+  y = fmaxf(y, dpp_f32<kDppXor1>(y));
+  {
+    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    x = fmaxf(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
+    y = fmaxf(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
+  }
+  {
+    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    x = fmaxf(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
+    y = fmaxf(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
+  }
+  return f2_make(x, y);
+}
+
 // Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals.
 // Every period is reduced over the wavefront on its own (pair_wave_sum): a few more VALU per period than the online
 // 8-period butterfly of the fp64 sweeps, but nothing is live across the folds -- the butterfly's pending partials
 // were spilled and reloaded in every pass (3.03 -> 2.82 ms for k_mbest_step1_pair at config 2).
-template <typename F>
+template <bool MX = false, typename F>
 __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N, const PGeomF* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end, int stride,
                                                 F&& consume) {
+  auto red = [](f2 v) { return MX ? pair_wave_max(v) : pair_wave_sum(v); };
   for (int i = i_first; i < i_end; i += stride) {
     const int p = plan[i].p, m = plan[i].m;
     if (m == 0) {
-      consume(pair_wave_sum(pair_partial_small(xs, N, p, geom[p])), p);
+      consume(red(pair_partial_small<MX>(xs, N, p, geom[p])), p);
     } else if (m == 1) {
       f2 part[3];
-      pair_pass_seg<1>(xs, p, geom, part);
-      consume(pair_wave_sum(part[0]), p);
+      pair_pass_seg<1, MX>(xs, p, geom, part);
+      consume(red(part[0]), p);
     } else if (m == 2) {
       f2 part[3];
-      pair_pass_seg<2>(xs, p, geom, part);
-      consume(pair_wave_sum(part[0]), p);
-      consume(pair_wave_sum(part[1]), 2 * p);
+      pair_pass_seg<2, MX>(xs, p, geom, part);
+      consume(red(part[0]), p);
+      consume(red(part[1]), 2 * p);
     } else {
       f2 part[3];
-      pair_pass_seg<4>(xs, p, geom, part);
-      consume(pair_wave_sum(part[0]), p);
-      consume(pair_wave_sum(part[1]), 2 * p);
-      consume(pair_wave_sum(part[2]), 4 * p);
+      pair_pass_seg<4, MX>(xs, p, geom, part);
+      consume(red(part[0]), p);
+      consume(red(part[1]), 2 * p);
+      consume(red(part[2]), 4 * p);
     }
   }
 }

@@ -214,3 +214,49 @@ def test_small_to_large_pair_kernel_equals_one_window_kernel():
     finally:
         single.close()
         pair.close()
+
+
+def test_best_correlation_pair_kernel_equals_one_window_kernel():
+    """k_best_correlation_pair against the one-window kernel (PH_BC_PAIR=0) and the oracle: periods, norm gains and
+    bases -- odd batches, lengths with ragged folds, a ratio that rejects some picks (zero rows), a zero window."""
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import PeriodEngine
+
+    old = os.environ.get("PH_BC_PAIR")
+    os.environ["PH_BC_PAIR"] = "0"
+    single = PeriodEngine(0)
+    os.environ["PH_BC_PAIR"] = "1"
+    pair = PeriodEngine(0)
+    if old is None:
+        del os.environ["PH_BC_PAIR"]
+    else:
+        os.environ["PH_BC_PAIR"] = old
+    def same(a, b):  # periods, bases, status bit for bit; the norm gains sum the squares in a different order
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert rel_err(b[1], a[1]) < 1e-13
+
+    try:
+        for n, w, kw in ((4096, 5, dict(num=3)), (1000, 3, dict(num=4, max_length=400, ratio=0.05)), (240, 7, dict(num=2)),
+                         (97, 1, dict(num=2)), (5000, 2, dict(num=2, ratio=0.2))):
+            x = multi_sinusoid_batch(900 + n, w, n)
+            if w > 2:
+                x[1] = 0.0  # status 1: every row zero
+            a = single.best_correlation(x, **kw)
+            b = pair.best_correlation(x, **kw)
+            same(a, b)
+            want = po.best_correlation(x[0], **kw)
+            assert np.array_equal(b[0][0], want[0]) and rel_err(b[1][0], want[1]) < TOL and rel_err(b[2][0], want[2]) < TOL
+        # many exact ties (values on a grid of 1/4): the survivor list overflows, every period is evaluated exactly
+        rng = np.random.default_rng(3)
+        x = np.round(rng.standard_normal((3, 1024)) * 4) / 4
+        a = single.best_correlation(x, 3)
+        b = pair.best_correlation(x, 3)
+        same(a, b)
+        for w in range(3):
+            want = po.best_correlation(x[w], 3)
+            assert np.array_equal(b[0][w], want[0]) and rel_err(b[2][w], want[2]) < TOL
+    finally:
+        single.close()
+        pair.close()
