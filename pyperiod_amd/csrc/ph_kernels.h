@@ -489,9 +489,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     if (tid == 0) ctl[0] = ctl[1] = 0;  // (read as `ncand` before the last barrier of the previous round)
     // ---- 1. screen of both windows (Periods.py:501-515 in float); values into the idle staging buffer
     f2* vals = reinterpret_cast<f2*>(stg);
-    pair_sweep_plan(pw, N, geomf, plan, wv, n_pass, nw, [&](f2 ss, int q) {
-      if (pair_lane() == 0) vals[q - p_lo] = ss;
-    });
+    pair_sweep_plan(
+        pw, N, geomf, plan, wv, n_pass, nw, [&](f2 ss, int q) {
+          if (pair_lane() == 0) vals[q - p_lo] = ss;
+        },
+        [&](f2 ss, int q_lower, int q_upper) {
+          const int l = pair_lane();
+          if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = ss;
+        });
     __syncthreads();
     PH_PAIR_MARK(0)
     // ---- 2. survivors of both windows: two passes over the values (a thread sees the same <= 2 entries twice)
@@ -1705,9 +1710,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     if ((run0 || run1) && P > 0) {
       // ---- screen: largest square of a residue sum per period, both windows (Periods.py:324-331 in float)
       f2* vals = reinterpret_cast<f2*>(stg);
-      pair_sweep_plan<true>(pw, N, geomf, plan, wv, n_pass, nw, [&](f2 v, int q) {
-        if (pair_lane() == 0) vals[q - p_lo] = v;
-      });
+      pair_sweep_plan<true>(
+          pw, N, geomf, plan, wv, n_pass, nw, [&](f2 v, int q) {
+            if (pair_lane() == 0) vals[q - p_lo] = v;
+          },
+          [&](f2 v, int q_lower, int q_upper) {
+            const int l = pair_lane();
+            if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = v;
+          });
       __syncthreads();
       const bool scr0 = run0 && st[8] != 0.0, scr1 = run1 && st[9] != 0.0;
       if (scr0 || scr1) {
@@ -2422,13 +2432,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 // whole greedy loop on the device.  One workgroup per window.  Per iteration:
 //   gamma-normalised all-p sweep of the residual (pass plan)  -> strongest period
 //   rows kept for it = Euler-phi mass its divisors add to the running divisor set
-//   Gram matrix A A^T extended by the new rows (integer co-occurrence counts, by folding the
-//   indicator rows), right-hand side extended by the fold of the data
-//   Cholesky solve in the window's HBM workspace, reconstruction A^T w, residual
+//   right-hand side A x extended by the fold of the data over the new rows
+//   A A^T w = A x by preconditioned conjugate gradients in LDS -- the Gram matrix (integer co-occurrence
+//   counts of the indicator rows) is never formed, its rows are regenerated inside the product (qo_offdiag)
+//   reconstruction A^T w, residual
 // The reference stops when rms(reconstruction) <= rms(data) * thresh (default test_function)
-// or when numpy.linalg.solve raises LinAlgError (here: a non-positive Cholesky pivot, a period
-// that adds no new rows, or a repeated period -- the cases that make the reference's matrix
-// singular).  counts[w] = {periods reported, blocks in the dictionary}.
+// or when numpy.linalg.solve raises LinAlgError (here: non-positive curvature or no convergence of the
+// solve, a period that adds no new rows, or a repeated period -- the cases that make the reference's
+// matrix singular).  counts[w] = {periods reported, blocks in the dictionary}.
 // ======================================================================================
 constexpr int kQoMaxBlocks = 64;
 constexpr int kQoPairTab = 16;  // dictionaries of up to this many blocks keep their pair constants in LDS

@@ -325,6 +325,39 @@ __device__ __forceinline__ f2 pair_wave_sum(f2 v) {
   return f2_make(x, y);
 }
 
+// Two values at once: afterwards lanes 0-31 hold the wavefront total of `a`, lanes 32-63 that of `b` -- one
+// v_permlane32_swap pairing replaces the half-wave level of two separate reductions (18 instead of 36 instructions for
+// the two periods of a two-class pass).
+template <bool MX>
+__device__ __forceinline__ f2 pair_wave_red2(f2 a, f2 b) {
+  auto op = [](float u, float v) { return MX ? fmaxf(u, v) : u + v; };
+  float x, y;
+  {
+    unsigned l0 = (unsigned)__float_as_int(a.x), l1 = (unsigned)__float_as_int(a.y);
+    unsigned h0 = (unsigned)__float_as_int(b.x), h1 = (unsigned)__float_as_int(b.y);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
+    x = op(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
+    y = op(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
+  }
+  x = op(x, dpp_f32<kDppRor8>(x));
+  y = op(y, dpp_f32<kDppRor8>(y));
+  x = op(x, dpp_f32<kDppHalfMirror>(x));
+  y = op(y, dpp_f32<kDppHalfMirror>(y));
+  x = op(x, dpp_f32<kDppXor2>(x));
+  y = op(y, dpp_f32<kDppXor2>(y));
+  x = op(x, dpp_f32<kDppXor1>(x));
+  y = op(y, dpp_f32<kDppXor1>(y));
+  {
+    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    x = op(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
+    y = op(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
+  }
+  return f2_make(x, y);
+}
+
 __device__ __forceinline__ f2 pair_wave_max(f2 v) {  // non-negative values (squares)
   float x = v.x, y = v.y;
   x = fmaxf(x, dpp_f32<kDppRor8>(x));
@@ -352,14 +385,16 @@ __device__ __forceinline__ f2 pair_wave_max(f2 v) {  // non-negative values (squ
   return f2_make(x, y);
 }
 
-// Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals.
+// Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals;
+// consume2(v, q_lower, q_upper) delivers two periods of a multi-class pass at once, lanes 0-31 holding the totals of
+// q_lower and lanes 32-63 those of q_upper.
 // Every period is reduced over the wavefront on its own (pair_wave_sum): a few more VALU per period than the online
 // 8-period butterfly of the fp64 sweeps, but nothing is live across the folds -- the butterfly's pending partials
 // were spilled and reloaded in every pass (3.03 -> 2.82 ms for k_mbest_step1_pair at config 2).
-template <bool MX = false, typename F>
+template <bool MX = false, typename F, typename F2>
 __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N, const PGeomF* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end, int stride,
-                                                F&& consume) {
+                                                F&& consume, F2&& consume2) {
   auto red = [](f2 v) { return MX ? pair_wave_max(v) : pair_wave_sum(v); };
   for (int i = i_first; i < i_end; i += stride) {
     const int p = plan[i].p, m = plan[i].m;
@@ -372,13 +407,11 @@ __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N
     } else if (m == 2) {
       f2 part[3];
       pair_pass_seg<2, MX>(xs, p, geom, part);
-      consume(red(part[0]), p);
-      consume(red(part[1]), 2 * p);
+      consume2(pair_wave_red2<MX>(part[0], part[1]), p, 2 * p);
     } else {
       f2 part[3];
       pair_pass_seg<4, MX>(xs, p, geom, part);
-      consume(red(part[0]), p);
-      consume(red(part[1]), 2 * p);
+      consume2(pair_wave_red2<MX>(part[0], part[1]), p, 2 * p);
       consume(red(part[2]), 4 * p);
     }
   }
