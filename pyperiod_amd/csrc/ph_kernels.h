@@ -1387,12 +1387,27 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       const int count = ct[2 + w];
       const Fold f(N, cand);
       double tsq = 0.0;
-      for (int j = tid; j < cand; j += blockDim.x) {
-        const double m = residue_mean(res, f, j, false);
-        const int cnt = f.count(j);
-        for (int r = 0; r < cnt; ++r) {
-          const double t = res[r * cand + j] - m;
-          tsq = fma(t, t, tsq);
+      // cand <= blockDim: one column per thread -- its mean stays in a register for the update below (these are the
+      // long columns, read through L2; a second row-order sum of them costs as much as the first)
+      const bool one_col = cand <= (int)blockDim.x;
+      double m_own = 0.0;
+      if (one_col) {
+        if (tid < cand) {
+          m_own = residue_mean(res, f, tid, false);
+          const int cnt = f.count(tid);
+          for (int r = 0; r < cnt; ++r) {
+            const double t = res[r * cand + tid] - m_own;
+            tsq = fma(t, t, tsq);
+          }
+        }
+      } else {
+        for (int j = tid; j < cand; j += blockDim.x) {
+          const double m = residue_mean(res, f, j, false);
+          const int cnt = f.count(j);
+          for (int r = 0; r < cnt; ++r) {
+            const double t = res[r * cand + j] - m;
+            tsq = fma(t, t, tsq);
+          }
         }
       }
       tsq = block_sum(tsq, red);
@@ -1406,7 +1421,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         double* brow = (bases_out && count < cap) ? bases_out + (gw * cap + count) * (int64_t)N : nullptr;
         double* dst = gres + gw * gstride;
         for (int j = tid; j < cand; j += blockDim.x) {
-          const double m = residue_mean(res, f, j, false);
+          const double m = one_col ? m_own : residue_mean(res, f, j, false);
           const int cnt = f.count(j);
           for (int r = 0; r < cnt; ++r) {
             const int n = r * cand + j;
