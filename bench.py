@@ -515,7 +515,9 @@ def main():
             k4_ms, _ = kernel_ms(eng.profile_read(), "k_small_to_large")
             eng.profile(False)
             checks["c4_capacity_ok"] = int(o4[3].abs().max().item()) == 0
-            tr4, ts4, _ = load_recorded_traffic("k_small_to_large")
+            tr4, ts4, _ = load_recorded_traffic("k_small_to_large_pair")
+            if tr4 is None:
+                tr4, ts4, _ = load_recorded_traffic("k_small_to_large")
             line["c4"] = {
                 "workload": f"config 4 on one GPU: small_to_large({C4_THRESH}), {total} windows x N={N_SAMPLES}, resident in HBM",
                 "n_gpus": 1,
