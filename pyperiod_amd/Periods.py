@@ -66,11 +66,13 @@ class Periods:
         p = int(p)
         if p > x.size:
             warn("invalid value encountered in divide", RuntimeWarning)  # 0/0 columns, Periods.py:194
+        if trunc_to_integer_multiple and getattr(data, "dtype", None) == np.float32:
+            # np.mean on the float32 rectangle keeps float32 (Periods.py:178-184): row-order float32 sums and one
+            # division -- what the library's float kernels do; nothing is computed in fp64 and cast back
+            x = np.ascontiguousarray(data, dtype=np.float32)
         out = default_engine().project_batch(
             x[None, :], [p], bool(trunc_to_integer_multiple), bool(orthogonalize)
         )[0, 0]
-        if trunc_to_integer_multiple and getattr(data, "dtype", None) == np.float32:
-            out = out.astype(np.float32)  # np.mean keeps float32 (Periods.py:180-184)
         return out[0:p] if return_single_period else out
 
     @staticmethod

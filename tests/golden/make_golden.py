@@ -5,7 +5,7 @@ reference never travels to the GPU box, the .npz files written here do.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections (default: all): kat project sweep small_to_large m_best best_correlation ramanujan
+Sections (default: all): kat project project_f32 sweep small_to_large m_best best_correlation ramanujan
 qoperiods orth_powers m_best_split ramanujan_c3 ramanujan_default ramanujan_weights
 qoperiods_c5 m_best_large_p.
 
@@ -131,6 +131,23 @@ def main():
                         assert np.array_equal(np.tile(single, n // p + 1)[:n], full)
                         out[key + "_single"] = single
         np.savez_compressed(os.path.join(HERE, "project.npz"), **out)
+
+    # ---------------------------------------------------------------- project, float32 windows in trunc mode
+    # (np.mean on the float32 rectangle keeps float32, Periods.py:178-184: row-order float32 sums, one division)
+    if want("project_f32"):
+        out = {}
+        for n in (97, 240, 4096):
+            x = multi_sinusoid_window(9, n, dtype=np.float32)
+            assert x.dtype == np.float32
+            out[f"x_{n}"] = x
+            for p in (2, 3, 7, 12, 64, 97, n // 2):
+                if p > n or p < 2:
+                    continue
+                for orth in (False, True):
+                    full = Periods.project(x, p, True, orth)
+                    assert full.dtype == np.float32
+                    out[f"n{n}_p{p}_o{int(orth)}"] = full
+        np.savez_compressed(os.path.join(HERE, "project_f32.npz"), **out)
 
     # ---------------------------------------------------------------- sweeps (N=4096, 4 windows)
     if want("sweep"):

@@ -529,3 +529,27 @@ def test_config2_full_size_properties(eng):
     for k, p in enumerate(pl):
         again = eng.project_batch(pr[:, k, :].copy(), [p])[:, 0, :]
         assert rel_err(again, pr[:, k, :]) < 1e-14
+
+
+def test_project_float32_trunc_keeps_float32_like_the_reference(golden):
+    """Trunc mode on a float32 window: the reference's np.mean works on the float32 rectangle (Periods.py:178-184) and
+    returns float32; the class surface runs the float kernels (row-order float32 sums, one division) instead of
+    computing in fp64 and casting.  Fixture: the reference itself on float32 input (tests/golden/make_golden.py)."""
+    from pyperiod_amd import Periods
+
+    g = golden("project_f32")
+    worst = 0.0
+    for n in (97, 240, 4096):
+        x = g[f"x_{n}"]
+        assert x.dtype == np.float32
+        for p in (2, 3, 7, 12, 64, 97, n // 2):
+            if p > n:
+                continue
+            for orth in (False, True):
+                want = g[f"n{n}_p{p}_o{int(orth)}"]
+                got = Periods.project(x, p, True, orth)
+                assert got.dtype == np.float32 and got.shape == want.shape
+                if not orth:
+                    assert np.array_equal(got, want), (n, p)  # the same float32 operations in the same order
+                worst = max(worst, rel_err(got, want))
+    assert worst < 5e-7  # orth: float32 subtractions of float32 projections, same order up to fused rounding

@@ -311,3 +311,16 @@ def test_elementwise_bar_on_sweeps(golden):
     x = multi_sinusoid_window(0, 4096)
     assert elem_err(po.sweep_norms(x, 2, 4096 // 3), g["plain_w0"]) < 1e-12
     assert elem_err(po.sweep_norms(x, 2, 4096 // 3, gamma=True), g["gamma_w0"]) < 1e-12
+
+
+def test_oracle_project_float32_trunc_matches_reference(golden):
+    """float32 windows in trunc mode stay float32 (np.mean on the float32 rectangle, Periods.py:178-184)."""
+    g = golden("project_f32")
+    for n in (97, 240, 4096):
+        x = g[f"x_{n}"]
+        for p in (2, 3, 7, 12, 64, 97, n // 2):
+            if p > n:
+                continue
+            for orth in (False, True):
+                got = po.project(x, p, True, orth)
+                assert got.dtype == np.float32 and np.array_equal(got, g[f"n{n}_p{p}_o{int(orth)}"]), (n, p, orth)
