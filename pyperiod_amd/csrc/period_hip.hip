@@ -901,8 +901,8 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   // Window-pair screen (k_small_to_large_pair): fp64 windows, plain projection, candidate periods below N.  Its LDS
   // is the pair window alone; the fp64 residuals live in an HBM workspace.
   const size_t lds_pair = carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(ph::kS2LBatch, 8) +
-                          carve_bytes(8, 8) + carve_bytes(8, 4);
-  const bool pair = c->s2l_pair && dtype == PH_F64 && !general && !gwin && n_periods < N &&
+                          carve_bytes(14, 8) + carve_bytes(8, 4) + carve_bytes(6, 4);
+  const bool pair = c->s2l_pair && dtype == PH_F64 && !general && !gwin && n_periods < N && c->sweep_block >= 512 &&
                     lds_pair <= (size_t)c->lds_limit;
   if (pair) {
     const size_t gstride = ph::win_stride((size_t)N);

@@ -1278,8 +1278,10 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   // per window w: st[w] ||residual||^2, st[2+w] periodic_norm(residual), st[4+w] periodic_norm(data), st[6+w] scale of
   // the float image; ct[w] next period to decide, ct[2+w] periods accepted, ct[4+w] candidate of this round,
   // ct[6+w] 1 once a period was accepted (the residual then lives in the workspace)
-  double* st = cv.take<double>(8);
+  // st[8+w], st[10+w], st[12+w]: A, rsq / A, 1 / scale^2 of the flag test below
+  double* st = cv.take<double>(14);
   int* ct = cv.take<int>(8);
+  int* cb = cv.take<int>(6);  // first flagged period of this round per window: three parities x two windows
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -1303,15 +1305,23 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     const double sc = uniform_f64(pair_pick_scale(rsq, N));
     for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] = exists ? (float)(src[n] * sc) : 0.0f;
     if (tid == 0) {
+      const double dnorm = sqrt(rsq) / sqrtN;  // data_norm, Periods.py:269
       st[w] = rsq;
-      st[2 + w] = st[4 + w] = sqrt(rsq) / sqrtN;  // data_norm, Periods.py:269
+      st[2 + w] = st[4 + w] = dnorm;
       st[6 + w] = sc;
+      const double A = (dnorm - (thresh - 1e-13) * dnorm) * sqrtN;
+      st[8 + w] = A;
+      st[10 + w] = rsq / A;
+      st[12 + w] = 1.0 / (sc * sc);
       ct[w] = exists ? 2 : n_periods + 1;
       ct[2 + w] = 0;
       ct[6 + w] = 0;
     }
   }
+  if (tid < 6) cb[tid] = 0x7fffffff;
   __syncthreads();
+  // Positions of the two windows: identical in every thread (they only change with values all threads read).
+  int pos0 = ct[0], pos1 = ct[1];
 #ifdef PH_S2L_TIMERS
   long long tp[4] = {0, 0, 0, 0};
   long long tp0 = wall_clock64();
@@ -1326,10 +1336,12 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 #define PH_S2LP_MARK(k)
 #endif
 
-  for (;;) {
-    const int p = min(ct[0], ct[1]);
+  for (int round = 0;; ++round) {
+    const int p = min(pos0, pos1);
     if (p > n_periods) break;
     const int hi = min(n_periods, p + kS2LBatch - 1);
+    int* cbr = cb + 2 * (round % 3);
+    if (tid < 2) cb[2 * ((round + 1) % 3) + tid] = 0x7fffffff;  // next round's slots (last read two barriers ago)
     // ---- screen [p, hi] on the float images of both windows
     for (int q = p + wv; q <= hi; q += nw) {
       f2 part[3];
@@ -1342,31 +1354,33 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       }
       if (pair_lane() == 0) psq[q - p] = v;
     }
-    __syncthreads();
-    if (wv == 0) {  // one lane per screened period; the first flagged one of each window is its candidate
-      const int q = p + lane;
-      const f2 v = q <= hi ? psq[lane] : f2_zero();
-      for (int w = 0; w < 2; ++w) {
-        bool flag = false;
-        if (q <= hi && q >= ct[w]) {
-          // decision bound of k_small_to_large with the float radius in place of the fp64 one: the screen has
-          // t_s = rsq - psq, the decision is taken on t_e = fl(sum (r - m)^2); |t_s - t_e| <= D = kappa rsq
-          const double rsq = st[w], rn = st[2 + w], dn = st[4 + w], sc = st[6 + w];
-          const double ps = (double)(w ? v.y : v.x) / (sc * sc);
-          const double tsq = fmax(rsq - ps, 0.0);
-          const double est = (rn - sqrt(tsq) / sqrtN) / dn;
-          const double kappa = pair_radius(geomf[q].rows, q) * (1.0 + 1e-9) + ((double)N / 256.0 + 32.0) * 2.220446049250313e-16;
-          const double D = kappa * rsq;
-          const double dsq = fmin(D / fmax(sqrt(tsq), 1e-300), sqrt(D));
-          const double err = dsq / sqrtN / dn + 1e-13;
-          flag = !(est + err <= thresh);  // NaN -> evaluate
-        }
-        const unsigned long long mask = __ballot(flag);
-        const int cnd = mask ? p + __ffsll((long long)mask) - 1 : -1;
-        if (lane == 0) {
-          ct[4 + w] = cnd;
-          if (cnd < 0 && ct[w] <= hi) ct[w] = hi + 1;  // nothing to evaluate: this window moves past the batch
-        }
+    // ---- which of this wavefront's periods has to be evaluated exactly?  Lane k < 4 looks at the wave's k-th period for
+    //      window 0, lane 4 + k for window 1 (a wave reads back only what it wrote).  Decision bound of
+    //      k_small_to_large with the float radius in place of the fp64 one: the screen has t_s = rsq - psq, the decision
+    //      is taken on t_e = fl(sum (r - m)^2), |t_s - t_e| <= D = kappa rsq.  With t = sqrt(t_s), the test
+    //      est + err > thresh for est = (rn - t / sqrtN) / dn, err <= D / (t sqrtN dn) + 1e-13 reads t - D / t < A,
+    //      A = (rn - (thresh - 1e-13) dn) sqrtN, which holds only below t* = (A + sqrt(A^2 + 4 D)) / 2 <= A + D / A:
+    //      flag unless rsq - psq >= (A + kappa rsq / A)^2 -- no square root, no division per period.
+    {
+      const int l = pair_lane();
+      const int w = (l >> 2) & 1;
+      const int q = p + wv + (l & 3) * nw;
+      bool flag = false;
+      if (l < 8 && q <= hi && q >= (w ? pos1 : pos0)) {
+        const f2 v = psq[q - p];
+        const double rsq = st[w], A = st[8 + w], c = st[10 + w];
+        const double ps = (double)(w ? v.y : v.x) * st[12 + w];
+        const double kappa = pair_radius(geomf[q].rows, q) * (1.0 + 1e-9) + ((double)N / 256.0 + 32.0) * 2.220446049250313e-16;
+        // upper bound of t*^2: (A + D / A)^2 for A > 0; for A <= 0 (the residual is already below thresh x data: nothing
+        // can be accepted except through the error term) t* <= min(sqrt(D), D / |A|)
+        const double kc = kappa * c, ts = A + kc;
+        const double lim = A > 0.0 ? ts * ts : fmin(kappa * rsq, kc * kc);
+        flag = !(rsq - ps >= lim * (1.0 + 1e-12));  // NaN -> evaluate
+      }
+      const unsigned long long mask = __ballot(flag);
+      if (l < 2) {
+        const unsigned m = (unsigned)(mask >> (4 * l)) & 0xFu;
+        if (m) atomicMin(&cbr[l], p + wv + (__ffs((int)m) - 1) * nw);
       }
     }
     __syncthreads();
@@ -1374,11 +1388,19 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 #ifdef PH_S2L_TIMERS
     nrounds += 1;
 #endif
-    if (ct[4] < 0 && ct[5] < 0) continue;  // the usual round: no candidate, positions already advanced by wave 0
+    const int c0 = cbr[0], c1 = cbr[1];
+    if (c0 == 0x7fffffff && c1 == 0x7fffffff) {  // the usual round: nothing to evaluate, both windows move past the batch
+      pos0 = pos0 <= hi ? hi + 1 : pos0;
+      pos1 = pos1 <= hi ? hi + 1 : pos1;
+      continue;
+    }
     // ---- exact evaluation of each window's candidate (Periods.py:274-286) on its fp64 residual
     for (int w = 0; w < 2; ++w) {
-      const int cand = ct[4 + w];
-      if (cand < 0) continue;  // (no candidate: finished, ahead of this batch, or moved past it by wave 0)
+      const int cand = w ? c1 : c0;
+      if (cand == 0x7fffffff) {  // no candidate: finished, ahead of this batch, or past it now
+        if (w ? pos1 <= hi : pos0 <= hi) (w ? pos1 : pos0) = hi + 1;
+        continue;
+      }
       __syncthreads();
       const int64_t gw = 2 * (int64_t)blockIdx.x + w;
       const bool moved = ct[6 + w] != 0;
@@ -1433,12 +1455,18 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         }
         __threadfence_block();
         __syncthreads();
+        double sc_now = sc;
         if (pair_usable(tsq) && tsq * sc * sc < 9.0e-13 * (double)N) {  // float image below 2^-20 RMS: renew its scale
           const double sc2 = uniform_f64(pair_pick_scale(tsq, N));
           s2l_pair_rescale<double>(pwf, w, N, (float)(sc2 / sc));
-          if (tid == 0) st[6 + w] = sc2;
+          sc_now = sc2;
         }
         if (tid == 0) {
+          st[6 + w] = sc_now;
+          const double A = (tn - (thresh - 1e-13) * dn) * sqrtN;
+          st[8 + w] = A;
+          st[10 + w] = tsq / A;
+          st[12 + w] = 1.0 / (sc_now * sc_now);
           if (count < cap) {
             periods_out[gw * cap + count] = cand;
             powers_out[gw * cap + count] = imposed;
@@ -1449,7 +1477,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
           st[2 + w] = tn;
         }
       }
-      if (tid == 0) ct[w] = cand + 1;
+      (w ? pos1 : pos0) = cand + 1;
       PH_S2LP_MARK(2)
     }
     __syncthreads();
