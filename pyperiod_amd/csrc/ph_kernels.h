@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 //   window ignores screen values below its own position (it re-screens what its partner still has to decide).
 //   LDS: 35 KB per pair at N = 4096 -> four workgroups of eight wavefronts per CU, i.e. eight windows per CU.
 // ======================================================================================
-template <typename T>
+// float image of window w of a pair times a power of two (its scale is renewed when the residual has collapsed)
 __device__ __forceinline__ void s2l_pair_rescale(float* __restrict__ pwf, int w, int N, float up) {
   for (int n = threadIdx.x; n < N; n += blockDim.x) pwf[2 * n + w] *= up;
 }
@@ -1276,9 +1276,9 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   double* red = cv.take<double>(kRedDoubles);
   f2* psq = cv.take<f2>(kS2LBatch);
   // per window w: st[w] ||residual||^2, st[2+w] periodic_norm(residual), st[4+w] periodic_norm(data), st[6+w] scale of
-  // the float image; ct[w] next period to decide, ct[2+w] periods accepted, ct[4+w] candidate of this round,
-  // ct[6+w] 1 once a period was accepted (the residual then lives in the workspace)
-  // st[8+w], st[10+w], st[12+w]: A, rsq / A, 1 / scale^2 of the flag test below
+  // the float image, st[8+w], st[10+w], st[12+w]: A, rsq / A, 1 / scale^2 of the flag test below; ct[w] first period
+  // (start of the walk), ct[2+w] periods accepted, ct[6+w] 1 once a period was accepted (the residual then lives in
+  // the workspace).  The positions of the two windows are kept in registers, identical in every thread.
   double* st = cv.take<double>(14);
   int* ct = cv.take<int>(8);
   int* cb = cv.take<int>(6);  // first flagged period of this round per window: three parities x two windows
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         double sc_now = sc;
         if (pair_usable(tsq) && tsq * sc * sc < 9.0e-13 * (double)N) {  // float image below 2^-20 RMS: renew its scale
           const double sc2 = uniform_f64(pair_pick_scale(tsq, N));
-          s2l_pair_rescale<double>(pwf, w, N, (float)(sc2 / sc));
+          s2l_pair_rescale(pwf, w, N, (float)(sc2 / sc));
           sc_now = sc2;
         }
         if (tid == 0) {
