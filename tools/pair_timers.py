@@ -1,3 +1,6 @@
+"""In-kernel phase timers of k_mbest_step1_pair: build a variant with -DPH_PAIR_TIMERS (hipcc ... -o _var/lib_timers.so) and run
+    PYPERIOD_AMD_LIB=$PWD/_var/lib_timers.so python3 tools/pair_timers.py
+The first six workgroups print screen / scan / load / exact / update times (100 MHz ticks), candidates and sweeps."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,5 @@
+"""In-kernel phase timers of k_qo_find (-DPH_QO_TIMERS build, loaded through PYPERIOD_AMD_LIB): sweep / rhs / CG / reconstruction
+times, CG iterations and dictionary sizes of the first twelve windows of a 64-window config-5 batch."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

@@ -1,3 +1,5 @@
+"""In-kernel phase timers of k_small_to_large and k_small_to_large_pair (-DPH_S2L_TIMERS build, loaded through PYPERIOD_AMD_LIB):
+screen / exact / update times, rounds, events and accepts of the first workgroups.  usage: s2l_timers.py [windows]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
