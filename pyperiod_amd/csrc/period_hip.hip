@@ -1204,14 +1204,12 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   const size_t lds = (gwin ? 0 : win_bytes) + carve_bytes((size_t)nw * q_hi, 8) +
                      carve_bytes((size_t)nw * std::max(1, q_hi / 2), 8);
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
-  const ph::PGeom* geom;
-  PH_TRY(prepare_geom(c, N, q_hi, &geom));
-  // tables: for every q the factors (I - P_d) of its projector (d = q / r for each prime r | q, with r and
-  // 1 / r), the scale (q / phi(q))^2, and the row-split geometry of the coset counts below 64
-  std::vector<int32_t> off(q_hi + 2, 0);
-  std::vector<ph::RamStep> steps;
-  std::vector<double> scale2(q_hi + 1, 0.0);
-  std::vector<ph::RamSmall> small(64, ph::RamSmall{0, 0});
+  // One 128-byte record per period (ph::RamJob): the factors (I - P_d) of its projector (d = q / r for each prime
+  // r | q, with 1 / r and the row-split geometry of a coset count below 64), the scale (q / phi(q))^2 and the
+  // geometry of its fold of the window.
+  if (q_hi >= 30030 || q_hi > 0xffff) return fail(PH_E_ARG, "ph_ramanujan_norms: q_hi=%d is beyond the record format", q_hi);
+  auto small_geom = [](int d) { return d >= 1 && d < 64 ? (64 / d) | (((65536 + d - 1) / d) << 8) : 0; };
+  std::vector<ph::RamJob> job((size_t)q_hi + 1);
   {
     std::vector<int32_t> phi(q_hi + 1);
     for (int i = 0; i <= q_hi; ++i) phi[i] = i;
@@ -1225,22 +1223,30 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
         primes_of[j].push_back(i);
       }
     }
-    for (int q = 0; q <= q_hi; ++q) {
-      off[q] = (int32_t)steps.size();
-      for (int r : primes_of[q]) steps.push_back(ph::RamStep{q / r, r, 1.0 / (double)r});
-      if (q >= 1) {
-        const double sc = (double)q / (double)phi[q];
-        scale2[q] = sc * sc;
+    for (int q = 1; q <= q_hi; ++q) {
+      ph::RamJob& J = job[q];
+      std::memset(&J, 0, sizeof(J));
+      J.q = q;
+      J.k = 1;
+      J.rows = (N + q - 1) / q;            // as PGeom: residues j < nfull own `rows` samples, the others rows - 1
+      J.nfull = N - (J.rows - 1) * q;
+      J.sm = small_geom(q);
+      const double sc = (double)q / (double)phi[q];
+      J.scale2 = sc * sc;
+      int ns = 0;
+      for (int r : primes_of[q]) {
+        J.st[ns].dr = (q / r) | (r << 16);
+        J.st[ns].sm = small_geom(q / r);
+        J.st[ns].inv_r = 1.0 / (double)r;
+        ++ns;
       }
+      J.flags = ns << 8;
     }
-    off[q_hi + 1] = (int32_t)steps.size();
-    if (steps.empty()) steps.push_back(ph::RamStep{1, 1, 1.0});
-    for (int d = 1; d < 64; ++d) small[d] = ph::RamSmall{64 / d, (65536 + d - 1) / d};
   }
   // Root plan: roots are the periods of (q_hi/2, q_hi]; every wanted q <= q_hi/2 becomes the child of one
   // of its multiples there (the least loaded one; children cost a strip fold and a filter, O(Q + q)).
   // Roots are dealt to the wavefronts in order of decreasing work.
-  std::vector<int32_t> tab;  // RamRoot records (4 ints each), then the children
+  std::vector<ph::RamJob> tab;  // root records, then the children
   int n_root = 0;
   if (q_lo <= q_hi) {
     const int half = q_hi / 2;
@@ -1259,35 +1265,24 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
       if (Q >= q_lo || !kids[Q].empty()) order.push_back(Q);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
     n_root = (int)order.size();
-    tab.resize((size_t)4 * n_root);
+    tab.resize((size_t)n_root);
     for (int i = 0; i < n_root; ++i) {
       const int Q = order[i];
-      tab[4 * i + 0] = Q;
-      tab[4 * i + 1] = (int32_t)((tab.size() - (size_t)4 * n_root) / 2);
+      ph::RamJob R = job[Q];
+      R.c0 = (int32_t)(tab.size() - (size_t)n_root);
       for (int q : kids[Q]) {
-        tab.push_back(q);
-        tab.push_back(Q / q);
+        ph::RamJob C = job[q];
+        C.k = Q / q;
+        tab.push_back(C);
       }
-      tab[4 * i + 2] = (int32_t)((tab.size() - (size_t)4 * n_root) / 2);
-      tab[4 * i + 3] = Q >= q_lo ? 1 : 0;
+      R.c1 = (int32_t)(tab.size() - (size_t)n_root);
+      R.flags |= Q >= q_lo ? 1 : 0;
+      tab[i] = R;
     }
   }
-  if (tab.empty()) tab.push_back(0);
-  // the small tables travel as raw int32 words through the cached table slots
-  static_assert(sizeof(ph::RamStep) == 16 && sizeof(ph::RamSmall) == 8, "table records are uploaded as int32 words");
-  std::vector<int32_t> aux((steps.size() * sizeof(ph::RamStep) + scale2.size() * sizeof(double) +
-                            small.size() * sizeof(ph::RamSmall)) / sizeof(int32_t));
-  const size_t steps_words = steps.size() * sizeof(ph::RamStep) / 4, scale_words = scale2.size() * 2;
-  std::memcpy(aux.data(), steps.data(), steps_words * 4);
-  std::memcpy(aux.data() + steps_words, scale2.data(), scale_words * 4);
-  std::memcpy(aux.data() + steps_words + scale_words, small.data(), small.size() * sizeof(ph::RamSmall));
-  const int *d_off, *d_aux, *d_tab;
-  PH_TRY(upload_table(c, T_AUX0, off.data(), off.size(), &d_off));
-  PH_TRY(upload_table(c, T_AUX1, aux.data(), aux.size(), &d_aux));
-  PH_TRY(upload_table(c, T_AUX2, tab.data(), tab.size(), &d_tab));
-  const ph::RamStep* d_steps = reinterpret_cast<const ph::RamStep*>(d_aux);
-  const double* d_scale2 = reinterpret_cast<const double*>(d_aux + steps_words);
-  const ph::RamSmall* d_small = reinterpret_cast<const ph::RamSmall*>(d_aux + steps_words + scale_words);
+  if (tab.empty()) tab.push_back(ph::RamJob{});
+  const int* d_tab;  // the records travel as raw int32 words through a cached table slot
+  PH_TRY(upload_table(c, T_AUX2, reinterpret_cast<const int32_t*>(tab.data()), tab.size() * (sizeof(ph::RamJob) / 4), &d_tab));
   Stage st(c, flags);
   const void* dx;
   void* dout;
@@ -1296,16 +1291,14 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   PH_HIP(hipMemsetAsync(dout, 0, (size_t)W * (q_hi + 1) * sizeof(double), c->stream));
   const dim3 grid((unsigned)W);
   if (n_root > 0) {
-    static_assert(sizeof(ph::RamRoot) == 4 * sizeof(int32_t), "RamRoot is uploaded as four ints");
-    const ph::RamRoot* d_roots = reinterpret_cast<const ph::RamRoot*>(d_tab);
-    const int2* d_child = reinterpret_cast<const int2*>(d_tab + (size_t)4 * n_root);
+    const ph::RamJob* d_roots = reinterpret_cast<const ph::RamJob*>(d_tab);
     PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
       using T = decltype(t);
       auto kernel = ph::k_ramanujan<T, decltype(lw)::value>;
       PH_TRY(allow_lds(kernel, lds));
       ProfScope ps_(c, "k_ramanujan");
-      hipLaunchKernelGGL(kernel, grid, dim3(nw * 64), lds, c->stream, (const T*)dx, N, q_hi, geom, d_roots, n_root, d_child,
-                         d_off, d_steps, d_scale2, d_small, (T*)gwin, (double*)dout);
+      hipLaunchKernelGGL(kernel, grid, dim3(nw * 64), lds, c->stream, (const T*)dx, N, q_hi, d_roots, n_root, d_roots + n_root,
+                         (T*)gwin, (double*)dout);
       return (int)PH_OK;
     }));
     PH_TRY(launch_check("k_ramanujan"));

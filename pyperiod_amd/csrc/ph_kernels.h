@@ -2224,12 +2224,28 @@ constexpr int kRamMaxWaves = 16;
 #define PH_RAM_U 4
 #endif
 
-struct RamRoot {
-  int q;       // root period, folded from the window
-  int c0, c1;  // its children: child_q[c0 .. c1)
-  int emit;    // 1: norms[q] is wanted (q >= q_lo)
+// Everything the kernel needs to know about one period, in ONE 128-byte record (two s_load_dwordx16): the strip
+// steps of a wavefront are chains of dependent LDS round trips with 3-4 wavefronts per SIMD to hide them, and the
+// round-2 tables (root -> child list -> step offsets -> steps -> row-split geometry, geometry, scale) put five
+// dependent scalar loads from memory in front of every period.
+struct RamStep {  // one factor (I - P_d) of E_q: d = q / r cosets of r elements
+  int dr;         // d | r << 16
+  int sm;         // row-split geometry of d < 64: G | inv16 << 8, G = 64 / d row groups, inv16 = ceil(65536 / d)
+  double inv_r;   // (lane / d == (lane * inv16) >> 16 for lane < 64)
 };
+constexpr int kRamMaxSteps = 5;  // distinct primes of q < 30030
+struct RamJob {
+  int q, k, nfull, rows;  // period; k = Q / q rows of a child in its root's strip; geometry of the fold of the window
+  int c0, c1, flags, sm;  // root: its children are jobs [c0, c1); flags = emit | nsteps << 8; sm: geometry of q < 64
+  double scale2, pad;     // (q / phi(q))^2
+  RamStep st[kRamMaxSteps];
+};
+static_assert(sizeof(RamJob) == 128, "RamJob is uploaded as 32 words");
 
+// Column sums of C chunks of the fold of the window to period p, stored into the strip.  (Taking the rows that do
+// not fill a block of U and the partial last row as ONE more batch of U x C loads, absent rows read from the zeroed
+// pad, was slower: 2.47 -> 2.59 ms at config 3 -- the batch always issues U x C loads, and the fold is paced by the
+// instructions it issues, not by the round trips of its tail.)
 template <typename T, int C, int U, bool LW>
 __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p, int rows, int nfull, int c0,
                                                  int lane, double* __restrict__ sbuf) {
@@ -2246,28 +2262,23 @@ __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p
   }
 }
 
-// Integer and reciprocal constants of the strip steps come from host tables: the kernel is paced by the
-// dependent strip steps of each wavefront (3-4 waves per SIMD), so every division taken out of those
-// chains counts.
-struct RamStep {  // one factor (I - P_d) of E_q: d = q / r cosets of r elements
-  int d;
-  int r;
-  double inv_r;
-};
-struct RamSmall {  // row-split geometry of a coset count d < 64
-  int G;      // 64 / d row groups
-  int inv16;  // ceil(65536 / d): lane / d == (lane * inv16) >> 16 for lane < 64
-};
-
 // Row-split coset sums of s[0 .. len) modulo d < 64 (d | len): lane = g d + i (g < G = 64 / d) adds
 // s[lane + k G d]; the G partial sums of a coset are combined with a shuffle tree.  Returns the coset
 // total in EVERY lane of the coset's column (lane mod d), 0 in the idle lanes >= G d.
-__device__ __forceinline__ double strip_cosets_small(const double* __restrict__ s, int len, int d, RamSmall sm,
-                                                     int lane) {
-  const int G = sm.G, L = G * d;
+__device__ __forceinline__ double strip_cosets_small(const double* __restrict__ s, int len, int d, int sm, int lane) {
+  const int G = sm & 255, inv16 = sm >> 8, L = G * d;
   double part = 0.0;
-  if (lane < L)
-    for (int idx = lane; idx < len; idx += L) part += s[idx];
+  if (lane < L) {
+    int idx = lane;
+    for (; idx + 3 * L < len; idx += 4 * L) {  // four loads in flight; the sum keeps its order
+      const double a = s[idx], b = s[idx + L], c = s[idx + 2 * L], e = s[idx + 3 * L];
+      part += a;
+      part += b;
+      part += c;
+      part += e;
+    }
+    for (; idx < len; idx += L) part += s[idx];
+  }
   int sft = 1;
   while (sft < G) sft <<= 1;
   for (sft >>= 1; sft >= 1; sft >>= 1) {
@@ -2275,18 +2286,62 @@ __device__ __forceinline__ double strip_cosets_small(const double* __restrict__ 
     const double o = __shfl(part, src & (kWave - 1), kWave);
     part += (src < L) ? o : 0.0;
   }
-  const int g = (lane * sm.inv16) >> 16;                  // lane / d
+  const int g = (lane * inv16) >> 16;                     // lane / d
   const double tot = __shfl(part, lane - g * d, kWave);  // the column's total sits in its first row group
   return lane < L ? tot : 0.0;
 }
 
+// The strip loops below run with compile-time trip counts where the counts are small (a coset of r = 2, 3, 5, 7
+// elements when d >= 64 and q <= 512; a child with k = Q / q <= 8 rows) and take two lane chunks per trip: the
+// kernel is paced by the dependent LDS round trips of each wavefront, so all loads of a trip are in flight
+// together.  Lanes past the end read element 0 and write nothing.  Sums keep the order of the generic loops.
+template <int K>
+__device__ __forceinline__ void strip_fold_fixed(const double* __restrict__ src, int q, double* __restrict__ dst,
+                                                 int lane) {
+  for (int c0 = 0; c0 < q; c0 += 2 * kWave) {
+    const int i0 = c0 + lane, i1 = i0 + kWave;
+    const bool ok0 = i0 < q, ok1 = i1 < q;
+    const double* p0 = src + (ok0 ? i0 : 0);
+    const double* p1 = src + (ok1 ? i1 : 0);
+    double v0[K], v1[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      v0[t] = p0[t * q];
+      v1[t] = p1[t * q];
+    }
+    double e0 = 0.0, o0 = 0.0, e1 = 0.0, o1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      if (t & 1) {
+        o0 += v0[t];
+        o1 += v1[t];
+      } else {
+        e0 += v0[t];
+        e1 += v1[t];
+      }
+    }
+    if (ok0) dst[i0] = e0 + o0;
+    if (ok1) dst[i1] = e1 + o1;
+  }
+}
+
 // dst[i] = sum_t src[i + t q], i < q  (len = k q): the fold of a folded strip.
-__device__ __forceinline__ void strip_fold(const double* __restrict__ src, int len, int q, int k,
-                                           const RamSmall* __restrict__ small, double* __restrict__ dst, int lane) {
+__device__ __forceinline__ void strip_fold(const double* __restrict__ src, int len, int q, int k, int sm,
+                                           double* __restrict__ dst, int lane) {
   if (q < 64) {
-    const double tot = strip_cosets_small(src, len, q, small[q], lane);
+    const double tot = strip_cosets_small(src, len, q, sm, lane);
     if (lane < q) dst[lane] = tot;
     return;
+  }
+  switch (k) {
+    case 2: strip_fold_fixed<2>(src, q, dst, lane); return;
+    case 3: strip_fold_fixed<3>(src, q, dst, lane); return;
+    case 4: strip_fold_fixed<4>(src, q, dst, lane); return;
+    case 5: strip_fold_fixed<5>(src, q, dst, lane); return;
+    case 6: strip_fold_fixed<6>(src, q, dst, lane); return;
+    case 7: strip_fold_fixed<7>(src, q, dst, lane); return;
+    case 8: strip_fold_fixed<8>(src, q, dst, lane); return;
+    default: break;
   }
   for (int i = lane; i < q; i += kWave) {
     double a0 = 0.0, a1 = 0.0;
@@ -2300,71 +2355,144 @@ __device__ __forceinline__ void strip_fold(const double* __restrict__ src, int l
   }
 }
 
-// One factor (I - P_d) of the projector, in place: every element of s[0 .. q) loses the mean of its
-// coset modulo d (r = q / d elements per coset).  Each lane reads and writes only its own elements.
-__device__ __forceinline__ void strip_remove_coset_means(double* __restrict__ s, int q, RamStep st,
-                                                         const RamSmall* __restrict__ small, int lane) {
-  const int d = st.d, r = st.r;
-  const double inv_r = st.inv_r;
-  if (d < 64) {
-    const RamSmall sm = small[d];
-    const int L = sm.G * d;
-    const double m = strip_cosets_small(s, q, d, sm, lane) * inv_r;
-    if (lane < L)
-      for (int idx = lane; idx < q; idx += L) s[idx] -= m;
-    return;
+// Sum of squares of the filtered strip, split by the count of the residue: norms[q] = (q / phi)^4 (cs all + full) with
+// cs = rows - 1 (every residue has at least rows - 1 samples, the residues below nfull one more).
+struct RamAcc {
+  double all = 0.0, full = 0.0;
+  __device__ __forceinline__ void add(double o, int j, int nfull) {
+    const double t = o * o;
+    all += t;
+    full += j < nfull ? t : 0.0;
   }
-  for (int i = lane; i < d; i += kWave) {
-    if (r <= 8) {  // the usual case (q <= 512): values stay in registers between the sum and the update
-      double v[8];
-      double m = 0.0;
+};
+
+// One factor (I - P_d) of the projector: every element of s[0 .. q) loses the mean of its coset modulo d (r = q / d
+// elements per coset); each lane reads and writes only its own elements.  LAST: the last factor of a period writes
+// nothing back -- the filtered values go straight into the sum of squares (one pass over the strip, its stores and
+// one wavefront sync less per period).
+template <int R, bool LAST>
+__device__ __forceinline__ void strip_step_fixed(double* __restrict__ s, int d, double inv_r, int lane, int nfull,
+                                                 RamAcc& acc) {
+  for (int c0 = 0; c0 < d; c0 += 2 * kWave) {
+    const int i0 = c0 + lane, i1 = i0 + kWave;
+    const bool ok0 = i0 < d, ok1 = i1 < d;
+    double* p0 = s + (ok0 ? i0 : 0);
+    double* p1 = s + (ok1 ? i1 : 0);
+    double v0[R], v1[R];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        v[t] = t < r ? s[i + t * d] : 0.0;
-        m += v[t];
+    for (int t = 0; t < R; ++t) {
+      v0[t] = p0[t * d];
+      v1[t] = p1[t * d];
+    }
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      m0 += v0[t];
+      m1 += v1[t];
+    }
+    m0 *= inv_r;
+    m1 *= inv_r;
+    if (ok0) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        if (LAST)
+          acc.add(v0[t] - m0, i0 + t * d, nfull);
+        else
+          p0[t * d] = v0[t] - m0;
       }
-      m *= inv_r;
+    }
+    if (ok1) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t < r) s[i + t * d] = v[t] - m;
-    } else {
-      double m = 0.0;
-      for (int t = 0; t < r; ++t) m += s[i + t * d];
-      m *= inv_r;
-      for (int t = 0; t < r; ++t) s[i + t * d] -= m;
+      for (int t = 0; t < R; ++t) {
+        if (LAST)
+          acc.add(v1[t] - m1, i1 + t * d, nfull);
+        else
+          p1[t * d] = v1[t] - m1;
+      }
     }
   }
 }
 
-// s holds S_q: apply E_q in place and reduce to norms[q] (all lanes get it).
-__device__ __forceinline__ double ram_emit(double* __restrict__ s, int q, const PGeom* __restrict__ geom,
-                                           const int* __restrict__ pr_off, const RamStep* __restrict__ steps,
-                                           const double* __restrict__ scale2, const RamSmall* __restrict__ small,
+template <bool LAST>
+__device__ __forceinline__ void strip_step(double* __restrict__ s, int q, const RamStep& st, int lane, int nfull,
+                                           RamAcc& acc) {
+  const int d = st.dr & 0xffff, r = st.dr >> 16;
+  const double inv_r = st.inv_r;
+  if (d < 64) {
+    const int L = (st.sm & 255) * d;
+    const double m = strip_cosets_small(s, q, d, st.sm, lane) * inv_r;
+    if (lane < L) {
+      int idx = lane;
+      for (; idx + 3 * L < q; idx += 4 * L) {
+        const double a = s[idx], b = s[idx + L], c = s[idx + 2 * L], e = s[idx + 3 * L];
+        if (LAST) {
+          acc.add(a - m, idx, nfull);
+          acc.add(b - m, idx + L, nfull);
+          acc.add(c - m, idx + 2 * L, nfull);
+          acc.add(e - m, idx + 3 * L, nfull);
+        } else {
+          s[idx] = a - m;
+          s[idx + L] = b - m;
+          s[idx + 2 * L] = c - m;
+          s[idx + 3 * L] = e - m;
+        }
+      }
+      for (; idx < q; idx += L) {
+        if (LAST)
+          acc.add(s[idx] - m, idx, nfull);
+        else
+          s[idx] -= m;
+      }
+    }
+    return;
+  }
+  switch (r) {  // r is prime; d >= 64 and q <= 512 leave 2, 3, 5, 7
+    case 2: strip_step_fixed<2, LAST>(s, d, inv_r, lane, nfull, acc); return;
+    case 3: strip_step_fixed<3, LAST>(s, d, inv_r, lane, nfull, acc); return;
+    case 5: strip_step_fixed<5, LAST>(s, d, inv_r, lane, nfull, acc); return;
+    case 7: strip_step_fixed<7, LAST>(s, d, inv_r, lane, nfull, acc); return;
+    default: break;
+  }
+  for (int i = lane; i < d; i += kWave) {
+    double m = 0.0;
+    for (int t = 0; t < r; ++t) m += s[i + t * d];
+    m *= inv_r;
+    for (int t = 0; t < r; ++t) {
+      if (LAST)
+        acc.add(s[i + t * d] - m, i + t * d, nfull);
+      else
+        s[i + t * d] -= m;
+    }
+  }
+}
+
+// s holds S_q: apply E_q (in place, but for the last factor) and reduce to norms[q] (all lanes get it).  `steps` is
+// the record's step list in memory: the next step is fetched (scalar load) while the current one runs.
+__device__ __forceinline__ double ram_emit(double* __restrict__ s, const RamJob& J, const RamStep* __restrict__ steps,
                                            int lane) {
-  for (int k = pr_off[q]; k < pr_off[q + 1]; ++k) {
-    strip_remove_coset_means(s, q, steps[k], small, lane);
+  const int q = J.q, nsteps = J.flags >> 8, nfull = J.nfull;
+  RamAcc acc;
+  RamStep cur = steps[0];
+#pragma unroll 1
+  for (int k = 0; k + 1 < nsteps; ++k) {
+    const RamStep nxt = steps[k + 1];
+    strip_step<false>(s, q, cur, lane, nfull, acc);
     ram_wave_sync();
+    cur = nxt;
   }
-  const int nfull = geom[q].nfull;
-  const double cf = (double)geom[q].rows, cs = cf - 1.0;
-  const double s2 = scale2[q];  // (q / phi(q))^2
-  double acc = 0.0;
-  for (int j = lane; j < q; j += kWave) {
-    const double o = s[j] * s2;
-    acc += (j < nfull ? cf : cs) * o * o;
+  if (nsteps > 0) {
+    strip_step<true>(s, q, cur, lane, nfull, acc);
+  } else {  // q == 1: E_1 is the identity
+    for (int j = lane; j < q; j += kWave) acc.add(s[j], j, nfull);
   }
-  return wave_sum(acc);
+  const double cs = (double)(J.rows - 1);
+  return wave_sum(cs * acc.all + acc.full) * (J.scale2 * J.scale2);  // out = (q / phi)^2 E_q S, norms = sum cnt out^2
 }
 
 template <typename T, bool LW>
 __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __restrict__ x, int N, int q_hi,
-                                                                const PGeom* __restrict__ geom,
-                                                                const RamRoot* __restrict__ roots, int n_root,
-                                                                const int2* __restrict__ child_q,
-                                                                const int* __restrict__ pr_off,
-                                                                const RamStep* __restrict__ steps,
-                                                                const double* __restrict__ scale2,
-                                                                const RamSmall* __restrict__ small, T* gwin,
+                                                                const RamJob* __restrict__ roots, int n_root,
+                                                                const RamJob* __restrict__ children, T* gwin,
                                                                 double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
@@ -2383,13 +2511,14 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
   __syncthreads();
 
   for (int i = wv; i < n_root; i += nw) {
-    const int Q = roots[i].q, c0 = roots[i].c0, c1 = roots[i].c1;
+    const RamJob R = roots[i];
+    const int Q = R.q;
     // ---- S_Q from the window
     if (Q < 64) {
       const double tot = wave_fold_small(xs, N, Q, lane);  // row-split path, S_Q[lane] in the lanes below Q
       if (lane < Q) sA[lane] = tot;
     } else {
-      const int rows = geom[Q].rows, nfull = geom[Q].nfull;
+      const int rows = R.rows, nfull = R.nfull;
       const int nchunks = (Q + 63) >> 6;
       int k0 = 0;
       // LDS capacity (window + strips) caps this kernel at 3-4 wavefronts per SIMD, so registers are
@@ -2404,16 +2533,16 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
     }
     ram_wave_sync();
     // ---- children: fold of the strip, filtered in the scratch strip
-    for (int c = c0; c < c1; ++c) {
-      const int q = child_q[c].x;  // .y = Q / q
-      strip_fold(sA, Q, q, child_q[c].y, small, sB, lane);
+    for (int c = R.c0; c < R.c1; ++c) {
+      const RamJob C = children[c];
+      strip_fold(sA, Q, C.q, C.k, C.sm, sB, lane);
       ram_wave_sync();
-      const double v = ram_emit(sB, q, geom, pr_off, steps, scale2, small, lane);
-      if (lane == 0) orow[q] = v;
+      const double v = ram_emit(sB, C, children[c].st, lane);
+      if (lane == 0) orow[C.q] = v;
       ram_wave_sync();  // sB is rewritten by the next child
     }
-    if (roots[i].emit) {
-      const double v = ram_emit(sA, Q, geom, pr_off, steps, scale2, small, lane);
+    if (R.flags & 1) {
+      const double v = ram_emit(sA, R, roots[i].st, lane);
       if (lane == 0) orow[Q] = v;
     }
     ram_wave_sync();  // sA is rewritten by the next root
