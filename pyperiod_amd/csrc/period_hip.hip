@@ -74,6 +74,7 @@ struct ph_ctx {
   bool step1_pair = true;  // PH_STEP1_PAIR=0: always the one-window fp64 kernel for m_best step 1
   bool s2l_pair = true;    // PH_S2L_PAIR=0: always the one-window kernel for small_to_large
   bool bc_pair = true;     // PH_BC_PAIR=0: always the one-window kernel for best_correlation
+  bool pair_chain = true;  // PH_PAIR_CHAIN=0: the window-pair kernels take the periods below 64 one pass each
   DevBuf twid;  // cos/sin(2 pi k / L), k < L, of the last best_frequency win_size
   int twid_len = -1;
   DevBuf bs_tab;  // Bluestein tables of the last (win_size, min(N, win_size)): M twiddles, chirp, FFT of the wrapped chirp
@@ -137,11 +138,26 @@ size_t elem_size(int dtype) { return dtype == PH_F64 ? 8 : 4; }
 // Pass plan of a norm sweep over [p_lo, p_hi]: every period is produced exactly once, either
 // by its own pass or as 2p / 4p of a smaller base period (see PassPlan in ph_device.h).
 // Periods below 64 use the row-split path one at a time (m = 0).
-std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m, bool mixed = true) {
+// `chains` (window-pair kernels): the periods up to 64 are taken in chains L, L/2, L/4, ... -- one row-split pass at
+// L yields them all (m = 8 + number of periods, see pair_chain_small in ph_pair.h) -- instead of one pass each.
+std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m, bool mixed = true, bool chains = false) {
   std::vector<ph::PassPlan> host;
   std::vector<char> covered((size_t)p_hi + 1, 0);
+  if (chains) {
+    for (int L = std::min(p_hi, 64); L >= p_lo; --L) {
+      if (covered[L]) continue;
+      int n = 0;
+      for (int q = L; q >= p_lo && q >= 1 && !covered[q]; q >>= 1) {
+        covered[q] = 1;
+        n += 1;
+        if (q & 1) break;
+      }
+      host.push_back(ph::PassPlan{L, 8 + n});
+    }
+    std::reverse(host.begin(), host.end());
+  }
   for (int p = p_lo; p <= p_hi; ++p) {
-    if (p < 64) {
+    if (p < 64 && !chains) {
       host.push_back(ph::PassPlan{p, 0});
       continue;
     }
@@ -156,10 +172,10 @@ std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m, bool mixed =
   // multi-class passes overlaps better than a phase of each.
   if (mixed && !std::getenv("PH_PLAN_SORTED")) {
     int count[5] = {0, 0, 0, 0, 0}, seen[5] = {0, 0, 0, 0, 0};
-    for (const auto& e : host) count[e.m] += 1;
+    for (const auto& e : host) count[e.m >= 8 ? 0 : e.m] += 1;
     std::vector<std::pair<double, size_t>> key(host.size());
     for (size_t i = 0; i < host.size(); ++i) {
-      const int m = host[i].m;
+      const int m = host[i].m >= 8 ? 0 : host[i].m;
       key[i] = {(seen[m] + 0.5) / count[m], i};
       seen[m] += 1;
     }
@@ -182,15 +198,18 @@ std::vector<ph::PassPlan> build_plan(int p_lo, int p_hi, int max_m, bool mixed =
 // and VALU-heavy passes overlaps better); otherwise ascending base period, i.e. the expensive multi-class
 // passes first and the cheap few-row singles last -- what a workgroup that walks the WHOLE plan between two
 // barriers wants (k_mbest_step1: shorter tail before the argmax barrier, -3 %).
-int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4, bool mixed = true) {
+int prepare_plan(ph_ctx* c, int p_lo, int p_hi, const ph::PassPlan** out, int* n_pass, int max_m = 4, bool mixed = true,
+                 bool chains = false) {
   max_m = std::min(max_m, c->plan_max_m);
+  chains = chains && c->pair_chain;
   if (!mixed) max_m += 8;  // cache key
+  if (chains) max_m += 16;
   if (c->plan.p && c->plan_lo == p_lo && c->plan_hi == p_hi && c->plan_m == max_m) {
     *out = static_cast<const ph::PassPlan*>(c->plan.p);
     *n_pass = c->plan_n;
     return PH_OK;
   }
-  const std::vector<ph::PassPlan> host = build_plan(p_lo, p_hi, mixed ? max_m : max_m - 8, mixed);
+  const std::vector<ph::PassPlan> host = build_plan(p_lo, p_hi, max_m & 7, mixed, chains);
   PH_HIP(hipStreamSynchronize(c->stream));
   PH_TRY(ensure(c, c->plan, std::max<size_t>(1, host.size()) * sizeof(ph::PassPlan)));
   if (!host.empty())
@@ -518,6 +537,7 @@ int ph_create(int device, ph_ctx** out) {
   if (const char* e = std::getenv("PH_STEP1_PAIR")) c->step1_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_S2L_PAIR")) c->s2l_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_BC_PAIR")) c->bc_pair = std::atoi(e) != 0;
+  if (const char* e = std::getenv("PH_PAIR_CHAIN")) c->pair_chain = std::atoi(e) != 0;
   if (const char* e = std::getenv("PH_STEP1_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
@@ -791,7 +811,10 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   PH_TRY(prepare_geom(c, N, max_length, &geom));
   const ph::PassPlan* plan;
   int n_pass;
-  PH_TRY(prepare_plan(c, min_length, max_length, &plan, &n_pass, 4, false));
+  // Window-pair screen (k_mbest_step1_pair): fp64 windows, plain projection, candidate periods below N, and room for
+  // the pair window plus one fp64 staging buffer in LDS.
+  const bool pair = pair_eligible(c, dtype, N, num, min_length, max_length, flags) && !gwin1 && !gwin2;
+  PH_TRY(prepare_plan(c, min_length, max_length, &plan, &n_pass, 4, false, pair));
   Stage st(c, flags);
   const void* dx;
   void *dper, *dpow, *dbases, *dstat;
@@ -812,10 +835,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const int max_iters = 12 * (P + num) + 64;
   const dim3 grid((unsigned)W);
-  // Window-pair screen (k_mbest_step1_pair): fp64 windows, plain projection, candidate periods below N, and room for
-  // the pair window plus one fp64 staging buffer in LDS.
   const size_t lds_pair = pair_lds_bytes(N, num, P);
-  const bool pair = pair_eligible(c, dtype, N, num, min_length, max_length, flags) && !gwin1 && !gwin2;
   if (pair) {
     const size_t gstride = ph::win_stride((size_t)N);
     PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));
@@ -960,7 +980,13 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   PH_TRY(check_lds(c, lds, N, "ph_best_correlation"));
   const ph::PassPlan* plan = nullptr;
   int n_pass = 0;
-  if (max_length - 1 >= 2) PH_TRY(prepare_plan(c, 2, max_length - 1, &plan, &n_pass));
+  // Window-pair screen (k_best_correlation_pair): fp64 windows, plain projection, pair window + staging buffer in LDS
+  const size_t lds_pair = 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
+                          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(8, 4) +
+                          carve_bytes(10, 8);
+  const bool pair = c->bc_pair && dtype == PH_F64 && !general && !gwin && max_length <= N && max_length - 1 >= 2 &&
+                    lds_pair <= (size_t)c->lds_limit;
+  if (max_length - 1 >= 2) PH_TRY(prepare_plan(c, 2, max_length - 1, &plan, &n_pass, 4, true, pair));
   const ph::PGeom* geom;
   PH_TRY(prepare_geom(c, N, std::max(max_length, 2), &geom));
   ph::Tables tb{};
@@ -975,12 +1001,6 @@ int ph_best_correlation(ph_ctx* c, const void* x, int dtype, int64_t W, int N, i
   PH_TRY(st.out(B_OUT3, status, (size_t)W * sizeof(int32_t), &dstat));
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
-  // Window-pair screen (k_best_correlation_pair): fp64 windows, plain projection, pair window + staging buffer in LDS
-  const size_t lds_pair = 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
-                          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(8, 4) +
-                          carve_bytes(10, 8);
-  const bool pair = c->bc_pair && dtype == PH_F64 && !general && !gwin && max_length <= N && max_length - 1 >= 2 &&
-                    lds_pair <= (size_t)c->lds_limit;
   if (pair) {
     const size_t gstride = ph::win_stride((size_t)N);
     PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));

@@ -491,7 +491,8 @@ __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, cons
 // every candidate period is produced exactly once (plan_passes in period_hip.hip).
 struct PassPlan {
   int p;  // base period
-  int m;  // 1, 2 or 4: the pass yields p, 2p (m >= 2) and 4p (m == 4); 0: p < 64, row-split path
+  int m;  // 1, 2 or 4: the pass yields p, 2p (m >= 2) and 4p (m == 4); 0: p < 64, row-split path;
+          // 8 + n (window-pair kernels only): p <= 64, row-split path yielding p, p/2, ..., p / 2^(n-1)
 };
 
 // ---------------------------------------------------------------- segmented passes

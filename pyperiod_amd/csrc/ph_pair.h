@@ -385,9 +385,73 @@ __device__ __forceinline__ f2 pair_wave_max(f2 v) {  // non-negative values (squ
   return f2_make(x, y);
 }
 
+// ---------------------------------------------------------------- chains of periods up to 64
+// The row-split pass at L <= 64 (lane l < L adds x[l + n L]: the fold to period L, contiguous reads) is the fold of
+// every divisor of L as well: S_{L/2}[l] = S_L[l] + S_L[l + L/2], and so on down the powers of two.  One pass of
+// N / L loads yields L, L/2, ..., L / 2^(nlev-1) -- the host plans 32 chains for the 63 periods up to 64 (PassPlan
+// m = 8 + nlev).  Two levels share one wavefront reduction (pair_wave_red2).  Any summation order is covered by
+// pair_radius.
+__device__ __forceinline__ f2 pair_shift_down(f2 v, int lane, int by) {  // v of lane + by (lanes that matter: < 64 - by)
+  const int addr = ((lane + by) & (kWave - 1)) << 2;
+  return f2_make(__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v.x))),
+                 __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v.y))));
+}
+
+template <bool MX>
+__device__ __forceinline__ f2 pair_chain_term(f2 tot, int lane, int q, const PGeomF& g) {
+  const float w = MX ? 1.0f : (lane < g.nfull) ? g.w_full : g.w_short;
+  return (lane < q) ? tot * tot * w : f2_zero();
+}
+
+template <bool MX, typename F, typename F2>
+__device__ __forceinline__ void pair_chain_small(const f2* __restrict__ xs, int N, int L, int nlev,
+                                                 const PGeomF* __restrict__ geom, F&& consume, F2&& consume2) {
+  const int lane = pair_lane();
+  PGeomF g = geom[L];
+  const int full = g.nfull == L ? g.rows : g.rows - 1;  // floor(N / L)
+  const bool on = lane < L;
+  const f2* ptr = xs + (on ? lane : 0);
+  f2 s0 = f2_zero(), s1 = f2_zero();
+  int r = 0;
+  for (; r + 4 <= full; r += 4) {
+    const f2 a = ptr[0], b = ptr[L], c = ptr[2 * L], d = ptr[3 * L];
+    s0 += a;
+    s1 += b;
+    s0 += c;
+    s1 += d;
+    ptr += 4 * L;
+  }
+  for (; r < full; ++r) {
+    s0 += ptr[0];
+    ptr += L;
+  }
+  const bool tail = on && (full * L + lane < N);
+  const f2 tv = xs[tail ? full * L + lane : 0];
+  f2 tot = s0 + s1 + (tail ? tv : f2_zero());
+  tot = on ? tot : f2_zero();
+  int q = L;
+  for (int lev = 0; lev < nlev; lev += 2) {
+    const f2 va = pair_chain_term<MX>(tot, lane, q, g);
+    if (lev + 1 < nlev) {
+      const int q2 = q >> 1;
+      const PGeomF g2 = geom[q2];
+      tot += pair_shift_down(tot, lane, q2);
+      const f2 vb = pair_chain_term<MX>(tot, lane, q2, g2);
+      consume2(pair_wave_red2<MX>(va, vb), q, q2);
+      if (lev + 2 < nlev) {
+        q = q2 >> 1;
+        g = geom[q];
+        tot += pair_shift_down(tot, lane, q);
+      }
+    } else {
+      consume(MX ? pair_wave_max(va) : pair_wave_sum(va), q);
+    }
+  }
+}
+
 // Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals;
-// consume2(v, q_lower, q_upper) delivers two periods of a multi-class pass at once, lanes 0-31 holding the totals of
-// q_lower and lanes 32-63 those of q_upper.
+// consume2(v, q_a, q_b) delivers two periods of a multi-class pass (or two levels of a chain) at once, lanes 0-31
+// holding the totals of q_a and lanes 32-63 those of q_b.
 // Every period is reduced over the wavefront on its own (pair_wave_sum): a few more VALU per period than the online
 // 8-period butterfly of the fp64 sweeps, but nothing is live across the folds -- the butterfly's pending partials
 // were spilled and reloaded in every pass (3.03 -> 2.82 ms for k_mbest_step1_pair at config 2).
@@ -398,7 +462,9 @@ __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N
   auto red = [](f2 v) { return MX ? pair_wave_max(v) : pair_wave_sum(v); };
   for (int i = i_first; i < i_end; i += stride) {
     const int p = plan[i].p, m = plan[i].m;
-    if (m == 0) {
+    if (m >= 8) {
+      pair_chain_small<MX>(xs, N, p, m - 8, geom, consume, consume2);
+    } else if (m == 0) {
       consume(red(pair_partial_small<MX>(xs, N, p, geom[p])), p);
     } else if (m == 1) {
       f2 part[3];
