@@ -69,6 +69,31 @@ def test_pair_kernel_equals_one_window_kernel(engines):
         assert rel_err(b[1], a[1]) < 1e-13 and rel_err(b[2], a[2]) < 1e-13
 
 
+def test_period_ranges_that_cut_the_chains_of_short_periods(engines):
+    """The pair screen takes the periods up to 64 in chains L, L/2, L/4, ... (one row-split pass each): ranges that start
+    inside a chain, end below 64, hold a single short period or none must give the lists of the fp64 kernel, and the
+    oracle's, with strong short-period components in the data so that the winners ARE chain members."""
+    single, pair = engines
+    rng = np.random.default_rng(11)
+    t = np.arange(4096)
+    x = np.stack([3.0 * rng.standard_normal(6)[t % 6] + 2.0 * rng.standard_normal(48)[t % 48] +
+                  1.5 * rng.standard_normal(35)[t % 35] + 0.2 * rng.standard_normal(4096) for _ in range(5)])
+    for lo, hi in ((2, 64), (2, 63), (2, 50), (5, 64), (7, 40), (13, 13), (33, 100), (48, 96), (3, 24), (64, 200), (17, 1365)):
+        for gamma in (False, True):
+            kw = dict(num=4, min_length=lo, max_length=hi, gamma=gamma)
+            a = single.m_best(x, want_sweeps=True, **kw)
+            b = pair.m_best(x, want_sweeps=True, **kw)
+            assert np.array_equal(a[0], b[0]), (lo, hi, gamma)
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+            assert rel_err(b[1], a[1]) < 1e-13 and rel_err(b[2], a[2]) < 1e-13
+            try:
+                want = po.m_best(x[0], 4, max_length=hi, min_length=lo, gamma=gamma)
+            except TypeError:  # the reference runs out of candidates (Periods.py:520/537): status != 0
+                assert b[3][0] != 0, (lo, hi, gamma)
+                continue
+            assert b[3][0] == 0 and np.array_equal(b[0][0], want[0]), (lo, hi, gamma)
+
+
 def _planted(n, p, q, b, seed=3):
     t = np.arange(n, dtype=np.float64)
     rng = np.random.default_rng(seed)
