@@ -483,6 +483,33 @@ __device__ __forceinline__ void wave_sweep(const T* __restrict__ xs, int N, cons
   }
 }
 
+// ---------------------------------------------------------------- wavefront priorities of co-resident workgroups
+// Two 16-wave workgroups share a CU in the window-pair kernels, and the instruction arbiter serves the OLDER
+// wavefronts first: at config 2 (512 workgroups = one per slot) the workgroup placed first on a CU ran its ten sweeps
+// in 1.8 ms while its neighbour starved and then needed the CU for another 0.8 ms on its own, with half the
+// wavefronts to hide latencies behind (tools/clocks.py, -DPH_CLOCKS).  Progress-dependent priorities keep the two in
+// step: the priority of the long, issue-bound phase is (-step) mod 3, so a workgroup one step behind its neighbour
+// wins the arbitration two times out of three, and the short barrier-bound phases of a step run at priority 3 (they
+// need few issue slots and every barrier in them waits for the slowest wavefront).  k_mbest_step1_pair 2.65 -> 2.44
+// ms, m_best_gamma 3.34 -> 3.07 ms.  -DPH_WAVE_PRIO=0 leaves the priorities alone.
+#ifndef PH_WAVE_PRIO
+#define PH_WAVE_PRIO 1
+#endif
+__device__ __forceinline__ void prio_by_progress(int step) {
+#if PH_WAVE_PRIO
+  switch (((3 << 20) - step) % 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(2); break;
+  }
+#endif
+}
+__device__ __forceinline__ void prio_short_phase() {
+#if PH_WAVE_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 // ---------------------------------------------------------------- multi-period passes
 // One pass over the window at base period p also yields the folds of 2p and 4p: row r of the
 // p-fold belongs to residue j + (r mod m) p of the (m p)-fold, so keeping one accumulator per

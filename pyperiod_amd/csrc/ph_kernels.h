@@ -482,10 +482,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
 #define PH_PAIR_MARK(k)
 #endif
   const float fn = (float)N;
+#ifdef PH_CLOCKS
+  const long long ck0 = clock64(), wk0 = wall_clock64();
+#endif
   for (;;) {
     __syncthreads();
     const bool act0 = ctl[10] != 0, act1 = ctl[11] != 0;
     if (!act0 && !act1) break;
+    prio_by_progress(max(ctl[8], ctl[9]));  // sweeps done: keeps the two workgroups of a CU in step (ph_device.h)
     if (tid == 0) ctl[0] = ctl[1] = 0;  // (read as `ncand` before the last barrier of the previous round)
     // ---- 1. screen of both windows (Periods.py:501-515 in float); values into the idle staging buffer
     f2* vals = reinterpret_cast<f2*>(stg);
@@ -499,6 +503,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
         });
     __syncthreads();
     PH_PAIR_MARK(0)
+    prio_short_phase();
     // ---- 2. survivors of both windows: two passes over the values (a thread sees the same <= 2 entries twice)
     {
       const bool scr0 = act0 && !ctl[12], scr1 = act1 && !ctl[13];
@@ -760,6 +765,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       PH_PAIR_MARK(4)
     }
   }
+#ifdef PH_CLOCKS
+  if ((blockIdx.x % 16) == 7 && tid == 0) {
+    const long long ck2 = clock64(), wk2 = wall_clock64();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    printf("PAIRWG %d start %lld end %lld cycles %lld MHz %.0f hwid %x xcc %x\n", (int)blockIdx.x, wk0, wk2, ck2 - ck0,
+           100.0 * (double)(ck2 - ck0) / (double)(wk2 - wk0), hwid, xcc & 15);
+  }
+#endif
 #ifdef PH_PAIR_TIMERS
   if (blockIdx.x < 6 && tid == 0)
     printf("pair timers (100 MHz ticks) screen %lld scan %lld load %lld exact %lld update %lld  candidates %d exact_all %d sweeps %d %d\n",
@@ -1750,6 +1765,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     const bool run0 = ctl[4] && ctl[2] == 0, run1 = ctl[5] && ctl[3] == 0;
     __syncthreads();
     if (tid == 0) ctl[0] = ctl[1] = 0;
+    prio_by_progress(it);
     if ((run0 || run1) && P > 0) {
       // ---- screen: largest square of a residue sum per period, both windows (Periods.py:324-331 in float)
       f2* vals = reinterpret_cast<f2*>(stg);
@@ -1761,6 +1777,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
             const int l = pair_lane();
             if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = v;
           });
+      prio_short_phase();
       __syncthreads();
       const bool scr0 = run0 && st[8] != 0.0, scr1 = run1 && st[9] != 0.0;
       if (scr0 || scr1) {
@@ -2505,10 +2522,16 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
   double* sB = cv.take<double>((size_t)nw * lenB) + (size_t)wv * lenB;  // scratch for one child
 
   const int64_t w = blockIdx.x;
+#ifdef PH_CLOCKS
+  const long long ck0 = clock64(), wk0 = wall_clock64();
+#endif
   load_window(x + w * (int64_t)N, xs, N);
   zero_pad(xs, N);
   double* orow = out + w * (int64_t)(q_hi + 1);
   __syncthreads();
+#ifdef PH_CLOCKS
+  const long long ck1 = clock64(), wk1 = wall_clock64();
+#endif
 
   for (int i = wv; i < n_root; i += nw) {
     const RamJob R = roots[i];
@@ -2547,6 +2570,13 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
     }
     ram_wave_sync();  // sA is rewritten by the next root
   }
+#ifdef PH_CLOCKS
+  if ((blockIdx.x == 7 || blockIdx.x == 2000) && threadIdx.x == 0) {
+    const long long ck2 = clock64(), wk2 = wall_clock64();
+    printf("k_ramanujan wg %d: load %lld cycles / %lld ticks(100MHz), work %lld cycles / %lld ticks -> %.0f MHz\n", (int)blockIdx.x,
+           ck1 - ck0, wk1 - wk0, ck2 - ck1, wk2 - wk1, 100.0 * (double)(ck2 - ck1) / (double)(wk2 - wk1));
+  }
+#endif
 }
 
 // ======================================================================================
