@@ -1222,7 +1222,7 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
     return fail(PH_E_ARG, "ph_ramanujan_norms: q_hi=%d needs %zu B of LDS per wavefront, device limit is %d B", q_hi, strip,
                 c->lds_limit);
   const size_t lds = (gwin ? 0 : win_bytes) + carve_bytes((size_t)nw * q_hi, 8) +
-                     carve_bytes((size_t)nw * std::max(1, q_hi / 2), 8);
+                     carve_bytes((size_t)nw * std::max(1, q_hi / 2), 8) + carve_bytes(1, 4);
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
   // One 128-byte record per period (ph::RamJob): the factors (I - P_d) of its projector (d = q / r for each prime
   // r | q, with 1 / r and the row-split geometry of a coset count below 64), the scale (q / phi(q))^2 and the

@@ -2520,6 +2520,7 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
   const int lenA = q_hi, lenB = q_hi / 2 > 0 ? q_hi / 2 : 1;
   double* sA = cv.take<double>((size_t)nw * lenA) + (size_t)wv * lenA;  // this wave's root fold S_Q
   double* sB = cv.take<double>((size_t)nw * lenB) + (size_t)wv * lenB;  // scratch for one child
+  int* next_root = cv.take<int>(1);  // roots are handed out as the wavefronts ask (decreasing work: longest first)
 
   const int64_t w = blockIdx.x;
 #ifdef PH_CLOCKS
@@ -2528,12 +2529,15 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
   load_window(x + w * (int64_t)N, xs, N);
   zero_pad(xs, N);
   double* orow = out + w * (int64_t)(q_hi + 1);
+  if (threadIdx.x == 0) *next_root = nw;
   __syncthreads();
 #ifdef PH_CLOCKS
   const long long ck1 = clock64(), wk1 = wall_clock64();
 #endif
 
-  for (int i = wv; i < n_root; i += nw) {
+  // A workgroup holds its CU alone (window + strips fill the LDS) and ends with its slowest wavefront: the roots are
+  // taken from a queue, not dealt round-robin -- no wavefront idles while another still has whole roots to do.
+  for (int i = wv; i < n_root;) {
     const RamJob R = roots[i];
     const int Q = R.q;
     // ---- S_Q from the window
@@ -2569,6 +2573,9 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
       if (lane == 0) orow[Q] = v;
     }
     ram_wave_sync();  // sA is rewritten by the next root
+    int nxt = 0;
+    if (lane == 0) nxt = atomicAdd(next_root, 1);
+    i = __builtin_amdgcn_readfirstlane(nxt);
   }
 #ifdef PH_CLOCKS
   if ((blockIdx.x == 7 || blockIdx.x == 2000) && threadIdx.x == 0) {
