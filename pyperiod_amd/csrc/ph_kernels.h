@@ -377,6 +377,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
 //   A window that is not finite / all zero, or whose survivor list overflows, takes every period through the
 //   exact evaluation instead (same decisions as k_mbest_step1, slower).
 // ======================================================================================
+#ifndef PH_PAIR_QUEUE
+#define PH_PAIR_QUEUE 1
+#endif
 constexpr int kPairListCap = 96;
 constexpr int kPairCoop = 6;  // up to this many survivors are evaluated by the whole workgroup, one after the other
 constexpr int kPairSmallP = 256;  // winners up to this period: means through LDS, subtraction by all threads
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     periods[k] = 0u;
   }
   for (int k = tid; k < 2 * SK; k += blockDim.x) skip[k] = 0u;
-  if (tid < 16) ctl[tid] = 0;
+  if (tid < 16) ctl[tid] = tid == 14 ? nw : 0;  // [14]: pass queue of the screen
   zero_pad(stg, N);
   for (int i = tid; i < kPad; i += blockDim.x) pw[N + i] = f2_zero();
   for (int w = 0; w < 2; ++w) {
@@ -500,10 +503,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
         [&](f2 ss, int q_lower, int q_upper) {
           const int l = pair_lane();
           if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = ss;
-        });
+        },
+        PH_PAIR_QUEUE ? &ctl[14] : nullptr);
     __syncthreads();
     PH_PAIR_MARK(0)
     prio_short_phase();
+    if (tid == 0) ctl[14] = nw;  // the pass queue of the next screen (barriers in between)
     // ---- 2. survivors of both windows: two passes over the values (a thread sees the same <= 2 entries twice)
     {
       const bool scr0 = act0 && !ctl[12], scr1 = act1 && !ctl[13];
@@ -1717,7 +1722,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   double* wbest = cv.take<double>(kMaxWaves);
   int* wbestp = cv.take<int>(kMaxWaves);
   int* list = cv.take<int>(2 * kPairListCap);
-  int* ctl = cv.take<int>(8);        // [w] survivors listed, [2+w] status, [4+w] window exists
+  int* ctl = cv.take<int>(8);        // [w] survivors listed, [2+w] status, [4+w] window exists, [6] pass queue
   double* st = cv.take<double>(10);  // [w] sum|r| (scaled), [2+w] scale, [4+w] og, [6+w] old_norm, [8+w] usable (1 / 0)
 
   const int tid = threadIdx.x;
@@ -1757,6 +1762,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       st[8 + w] = pair_usable(a2) ? 1.0 : 0.0;
       ctl[2 + w] = 0;
       ctl[4 + w] = exists ? 1 : 0;
+      ctl[6] = nw;  // pass queue of the screen
     }
   }
   __syncthreads();
@@ -1776,9 +1782,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
           [&](f2 v, int q_lower, int q_upper) {
             const int l = pair_lane();
             if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = v;
-          });
+          },
+          PH_PAIR_QUEUE ? &ctl[6] : nullptr);
       prio_short_phase();
       __syncthreads();
+      if (tid == 0) ctl[6] = nw;  // for the next screen (barriers in between)
       const bool scr0 = run0 && st[8] != 0.0, scr1 = run1 && st[9] != 0.0;
       if (scr0 || scr1) {
         const double u0 = 1.25 * 5.9604644775390625e-08 * st[0], u1 = 1.25 * 5.9604644775390625e-08 * st[1];

@@ -458,10 +458,20 @@ __device__ __forceinline__ void pair_chain_small(const f2* __restrict__ xs, int 
 template <bool MX = false, typename F, typename F2>
 __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N, const PGeomF* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end, int stride,
-                                                F&& consume, F2&& consume2) {
+                                                F&& consume, F2&& consume2, int* __restrict__ queue = nullptr) {
   auto red = [](f2 v) { return MX ? pair_wave_max(v) : pair_wave_sum(v); };
-  for (int i = i_first; i < i_end; i += stride) {
-    const int p = plan[i].p, m = plan[i].m;
+  // `queue` (an LDS counter the caller has set to `stride`, the number of wavefronts): the passes are taken in plan
+  // order by whichever wavefront is free -- the passes differ in cost and the sweep ends at a barrier.
+  for (int i = i_first; i < i_end;) {
+    int nxt = i + stride;
+    if (queue) {
+      int t = 0;
+      if (pair_lane() == 0) t = atomicAdd(queue, 1);
+      nxt = __builtin_amdgcn_readfirstlane(t);
+    }
+    const int i_now = i;
+    i = nxt;
+    const int p = plan[i_now].p, m = plan[i_now].m;
     if (m >= 8) {
       pair_chain_small<MX>(xs, N, p, m - 8, geom, consume, consume2);
     } else if (m == 0) {
