@@ -332,7 +332,7 @@ def main():
     # =============================== config 2 (headline, every N) ===============================
     x = torch.from_numpy(x2_host).to(dev)
     P = N_SAMPLES // 3 - 2 + 1
-    n_pass, n_per = eng.sweep_plan_info(2, N_SAMPLES // 3)
+    n_pass, n_per = eng.m_best_plan_info(N_SAMPLES, NUM_PERIODS)
     assert n_per == P
     win_per_wg, lds_elem = eng.m_best_info(N_SAMPLES, NUM_PERIODS)
 

@@ -119,6 +119,13 @@ int ph_sweep_plan_info(ph_ctx* ctx, int p_lo, int p_hi, int* n_pass, int* n_peri
 int ph_m_best_info(ph_ctx* ctx, int dtype, int N, int num, int min_length, int max_length, unsigned flags,
                    int* windows_per_workgroup, int* lds_bytes_per_sample);
 
+/* Measurement helper: the pass plan that step-1 kernel walks per sweep over [min_length, max_length] (max_length < 0:
+ * N / 3, Periods.py:486): n_pass passes over the window for n_periods candidate periods.  The window-pair kernel
+ * takes the periods up to 64 in chains (one row-split pass at L yields L, L/2, L/4, ...), so its plan is shorter
+ * than ph_sweep_plan_info's. */
+int ph_m_best_plan_info(ph_ctx* ctx, int dtype, int N, int num, int min_length, int max_length, unsigned flags,
+                        int* n_pass, int* n_periods);
+
 /* ---- Periods.periodic_norm over a batch (Periods.py:221-241) ---------------------------
  * out[w] = ||x[w]||_2 / sqrt(N), additionally / sqrt(p) when p > 0.  Any N. */
 int ph_periodic_norm(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, int p,

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ph_max_window": [_vp, _i, _u, C.POINTER(_i)],
     "ph_sweep_plan_info": [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i)],
     "ph_m_best_info": [_vp, _i, _i, _i, _i, _i, _u, C.POINTER(_i), C.POINTER(_i)],
+    "ph_m_best_plan_info": [_vp, _i, _i, _i, _i, _i, _u, C.POINTER(_i), C.POINTER(_i)],
     "ph_periodic_norm": [_vp, _vp, _i, _i64, _i, _i, _u, _vp],
     "ph_project_batch": [_vp, _vp, _i, _i64, _i, _pi32, _i, _pi32, _pi32, _i, _u, _vp],
     "ph_sweep": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _pi32, _pi32, _i, _u, _vp],

@@ -612,6 +612,19 @@ int ph_m_best_info(ph_ctx* c, int dtype, int N, int num, int min_length, int max
   return PH_OK;
 }
 
+int ph_m_best_plan_info(ph_ctx* c, int dtype, int N, int num, int min_length, int max_length, unsigned flags, int* n_pass,
+                        int* n_periods) {
+  if (!c || !n_pass || !n_periods) return fail(PH_E_ARG, "NULL argument");
+  if (dtype != PH_F64 && dtype != PH_F32) return fail(PH_E_ARG, "dtype must be PH_F64 or PH_F32");
+  if (max_length < 0) max_length = N / 3;
+  if (min_length < 1 || max_length < min_length)
+    return fail(PH_E_ARG, "need 1 <= min_length <= max_length (got %d, %d)", min_length, max_length);
+  const bool pair = pair_eligible(c, dtype, N, num, min_length, max_length, flags);
+  *n_pass = (int)build_plan(min_length, max_length, c->plan_max_m, false, pair && c->pair_chain).size();
+  *n_periods = max_length - min_length + 1;
+  return PH_OK;
+}
+
 int ph_sync(ph_ctx* c) {
   if (!c) return fail(PH_E_ARG, "ctx is NULL");
   PH_HIP(hipStreamSynchronize(c->stream));

@@ -231,6 +231,15 @@ class PeriodEngine:
                                             C.byref(wpw), C.byref(bps)))
         return wpw.value, bps.value
 
+    def m_best_plan_info(self, n, num=5, max_length=None, min_length=2, dtype=np.float64, trunc=False, orth=False):
+        """(passes, periods) of one sweep of the step-1 kernel m_best would run (the window-pair kernel takes the
+        periods up to 64 in chains, so it needs fewer passes than sweep_plan_info reports for the fp64 sweeps)."""
+        n_pass, n_per = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.ph_m_best_plan_info(self._ctx, _NP_DTYPES[np.dtype(dtype)], int(n), int(num), int(min_length),
+                                                 int(n // 3 if max_length is None else max_length),
+                                                 self._flags(trunc, orth), C.byref(n_pass), C.byref(n_per)))
+        return n_pass.value, n_per.value
+
     def m_best(self, x, num=5, max_length=None, min_length=2, gamma=False, trunc=False, orth=False, want_sweeps=False):
         """-> periods (W,num) uint32, powers (W,num) f64, bases (W,num,N), status (W) int32
         [, n_sweeps (W) int32 when want_sweeps]."""

@@ -70,6 +70,8 @@ int main() {
   EXPECT(ph_sweep_plan_info(c, 0, 5, &a, &b), PH_E_ARG);
   EXPECT(ph_m_best_info(c, PH_F64, 4096, 10, 2, -1, 0, &a, &b), PH_OK);
   EXPECT(ph_m_best_info(c, PH_F32, 4096, 10, 2, 1365, PH_FLAG_TRUNC, &a, &b), PH_OK);
+  EXPECT(ph_m_best_plan_info(c, PH_F64, 4096, 10, 2, -1, 0, &a, &b), PH_OK);
+  EXPECT(ph_m_best_plan_info(c, PH_F64, 4096, 10, 9, 3, 0, &a, &b), PH_E_ARG);
   EXPECT(ph_profile_enable(c, 1), PH_OK);
 
   const int sizes[][2] = {{1, 7}, {3, 100}, {5, 1000}, {2, 4096}, {1, 9000}, {1, 20000}};
