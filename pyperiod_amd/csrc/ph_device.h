@@ -504,6 +504,11 @@ __device__ __forceinline__ void prio_by_progress(int step) {
   }
 #endif
 }
+__device__ __forceinline__ void prio_long_phase() {
+#if PH_WAVE_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
 __device__ __forceinline__ void prio_short_phase() {
 #if PH_WAVE_PRIO
   __builtin_amdgcn_s_setprio(3);

@@ -1362,6 +1362,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     const int hi = min(n_periods, p + kS2LBatch - 1);
     int* cbr = cb + 2 * (round % 3);
     if (tid < 2) cb[2 * ((round + 1) % 3) + tid] = 0x7fffffff;  // next round's slots (last read two barriers ago)
+    prio_long_phase();  // the events below wait on L2 round trips and run ahead of the other workgroups' screens (-1.6 %)
     // ---- screen [p, hi] on the float images of both windows
     for (int q = p + wv; q <= hi; q += nw) {
       f2 part[3];
@@ -1414,6 +1415,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       pos1 = pos1 <= hi ? hi + 1 : pos1;
       continue;
     }
+    prio_short_phase();
     // ---- exact evaluation of each window's candidate (Periods.py:274-286) on its fp64 residual
     for (int w = 0; w < 2; ++w) {
       const int cand = w ? c1 : c0;
