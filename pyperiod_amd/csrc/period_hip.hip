@@ -1221,12 +1221,22 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   const size_t win_bytes = carve_bytes(N + kPad, sz);
   auto waves_for = [&](size_t room) { return (int)std::min<size_t>(ph::kRamMaxWaves, room / strip); };
   const size_t limit = (size_t)c->lds_limit;
-  int nw = win_bytes + 64 < limit ? waves_for(limit - win_bytes - 64) : 0;
+  int nw = win_bytes < limit ? waves_for(limit - win_bytes) : 0;
+  int pad = kPad;
+  // The zeroed pad behind the window serves the row-split fold of roots below 64 (q_hi < 128) only; a fold of a root
+  // >= 64 merely reads up to 255 elements past the window for lanes whose sums it discards.  Without the pad those reads
+  // land in the strips -- and at config 3 window + 16 x 6 KB of strips are exactly the 160 KB of the CU.
+  const size_t win_bare = carve_bytes(N, sz);
+  if (q_hi >= 128 && nw >= 2 && nw < ph::kRamMaxWaves && waves_for(limit - win_bare) > nw) {
+    nw = waves_for(limit - win_bare);
+    pad = 0;
+  }
   void* gwin = nullptr;
   if (nw < 4) {
-    const int nw_hbm = waves_for(limit - 64);
+    const int nw_hbm = waves_for(limit);
     if (nw_hbm > nw) {
       nw = nw_hbm;
+      pad = kPad;
       PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * ph::win_stride(N + kPad) * sz));
       gwin = c->buf[B_GWIN].p;
     }
@@ -1234,8 +1244,8 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
   if (nw < 1)
     return fail(PH_E_ARG, "ph_ramanujan_norms: q_hi=%d needs %zu B of LDS per wavefront, device limit is %d B", q_hi, strip,
                 c->lds_limit);
-  const size_t lds = (gwin ? 0 : win_bytes) + carve_bytes((size_t)nw * q_hi, 8) +
-                     carve_bytes((size_t)nw * std::max(1, q_hi / 2), 8) + carve_bytes(1, 4);
+  const size_t lds = (gwin ? 0 : pad ? win_bytes : win_bare) + carve_bytes((size_t)nw * q_hi, 8) +
+                     carve_bytes((size_t)nw * std::max(1, q_hi / 2), 8);
   PH_TRY(check_lds(c, lds, N, "ph_ramanujan_norms"));
   // One 128-byte record per period (ph::RamJob): the factors (I - P_d) of its projector (d = q / r for each prime
   // r | q, with 1 / r and the row-split geometry of a coset count below 64), the scale (q / phi(q))^2 and the
@@ -1331,7 +1341,7 @@ int ph_ramanujan_norms(ph_ctx* c, const void* x, int dtype, int64_t W, int N, in
       PH_TRY(allow_lds(kernel, lds));
       ProfScope ps_(c, "k_ramanujan");
       hipLaunchKernelGGL(kernel, grid, dim3(nw * 64), lds, c->stream, (const T*)dx, N, q_hi, d_roots, n_root, d_roots + n_root,
-                         (T*)gwin, (double*)dout);
+                         (T*)gwin, pad, (double*)dout);
       return (int)PH_OK;
     }));
     PH_TRY(launch_check("k_ramanujan"));

@@ -2519,27 +2519,30 @@ __device__ __forceinline__ double ram_emit(double* __restrict__ s, const RamJob&
 template <typename T, bool LW>
 __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __restrict__ x, int N, int q_hi,
                                                                 const RamJob* __restrict__ roots, int n_root,
-                                                                const RamJob* __restrict__ children, T* gwin,
+                                                                const RamJob* __restrict__ children, T* gwin, int pad,
                                                                 double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
-  T* xs = window_buf<T, LW>(cv, gwin, N + kPad);
+  // pad == 0 (the host drops the zeroed pad when that makes room for one more wavefront; roots >= 64 only): the reads
+  // of a fold past the end of the window land in the strips -- they belong to lanes whose sums are discarded
+  T* xs = window_buf<T, LW>(cv, gwin, N + pad);
   const int nw = blockDim.x >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
   const int lenA = q_hi, lenB = q_hi / 2 > 0 ? q_hi / 2 : 1;
   double* sA = cv.take<double>((size_t)nw * lenA) + (size_t)wv * lenA;  // this wave's root fold S_Q
   double* sB = cv.take<double>((size_t)nw * lenB) + (size_t)wv * lenB;  // scratch for one child
-  int* next_root = cv.take<int>(1);  // roots are handed out as the wavefronts ask (decreasing work: longest first)
 
   const int64_t w = blockIdx.x;
 #ifdef PH_CLOCKS
   const long long ck0 = clock64(), wk0 = wall_clock64();
 #endif
   load_window(x + w * (int64_t)N, xs, N);
-  zero_pad(xs, N);
+  if (pad) zero_pad(xs, N);
   double* orow = out + w * (int64_t)(q_hi + 1);
-  if (threadIdx.x == 0) *next_root = nw;
+  // the root queue: orow[0] (0 is never a period) is zero on entry and is put back to zero at the end -- an LDS
+  // counter would cost the 16 bytes that decide between 15 and 16 wavefronts at config 3
+  int* next_root = reinterpret_cast<int*>(orow);
   __syncthreads();
 #ifdef PH_CLOCKS
   const long long ck1 = clock64(), wk1 = wall_clock64();
@@ -2548,6 +2551,8 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
   // A workgroup holds its CU alone (window + strips fill the LDS) and ends with its slowest wavefront: the roots are
   // taken from a queue, not dealt round-robin -- no wavefront idles while another still has whole roots to do.
   for (int i = wv; i < n_root;) {
+    int nxt = 0;
+    if (lane == 0) nxt = atomicAdd(next_root, 1);  // asked for now, needed after this root: the HBM round trip hides
     const RamJob R = roots[i];
     const int Q = R.q;
     // ---- S_Q from the window
@@ -2583,10 +2588,10 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
       if (lane == 0) orow[Q] = v;
     }
     ram_wave_sync();  // sA is rewritten by the next root
-    int nxt = 0;
-    if (lane == 0) nxt = atomicAdd(next_root, 1);
-    i = __builtin_amdgcn_readfirstlane(nxt);
+    i = nw + __builtin_amdgcn_readfirstlane(nxt);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) orow[0] = 0.0;
 #ifdef PH_CLOCKS
   if ((blockIdx.x == 7 || blockIdx.x == 2000) && threadIdx.x == 0) {
     const long long ck2 = clock64(), wk2 = wall_clock64();
