@@ -895,6 +895,20 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   zero_pad(rowbuf, N);
   __syncthreads();
 
+#ifdef PH_STEP2_TIMERS
+  long long t2[6] = {0, 0, 0, 0, 0, 0};
+  long long t20 = wall_clock64();
+  const long long t2start = t20;
+  int nrows_done = 0, nsplit = 0;
+#define PH_S2_MARK(k)                      \
+  {                                        \
+    const long long now_ = wall_clock64(); \
+    t2[k] += now_ - t20;                   \
+    t20 = now_;                            \
+  }
+#else
+#define PH_S2_MARK(k)
+#endif
   const int gdiv = gamma ? stale_p : 0;
   int i = (status[w] == 0) ? 0 : num;  // a window whose step 1 failed is passed through
   // a row whose period has no proper divisor (a prime) has nothing to test and is not even read
@@ -927,6 +941,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     }
   };
   i = next_row(i);
+  PH_S2_MARK(0)
   while (i < num) {
     const int per = (int)periods[i];
     const int a = fa[i], b = fb[i];
@@ -962,6 +977,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
       if (!general && tid < b - a) ffac[tid] = tb.fac_q[a + tid];
     }
     __syncthreads();
+    PH_S2_MARK(1)
     const int inext = next_row(i + 1);
     stage_row = -1;
     if (LW && short_row && inext < num) {  // LW == false: rowbuf is an HBM workspace, nothing to stage into
@@ -1004,8 +1020,10 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         ram_wave_sync();  // the slot is rewritten for this wavefront's next factor
         if (lane == 0) fvals[k] = periodic_norm_from_sq(ss, N, gdiv);
       }
+      PH_S2_MARK(2)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA of the next row has landed
       __syncthreads();
+      PH_S2_MARK(3)
       // rows below i are final: their stores drain behind the scan below and the next row's folds (issued
       // here, after the wait above, so that the DMA is not held up behind them)
       flush_rows(i);
@@ -1041,6 +1059,11 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     }
     const int s_here = slot[i], s_last = slot[num - 1];
     __syncthreads();
+    PH_S2_MARK(4)
+#ifdef PH_STEP2_TIMERS
+    nrows_done += 1;
+    nsplit += split ? 1 : 0;
+#endif
     if (!split) {
       i = inext;
       continue;
@@ -1090,6 +1113,12 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   }
   __syncthreads();
   flush_rows(num);
+  PH_S2_MARK(5)
+#ifdef PH_STEP2_TIMERS
+  if ((blockIdx.x % 128) == 5 && tid == 0)
+    printf("step2 wg %d (100 MHz ticks): init %lld stage %lld folds %lld dma+barrier %lld flush+scan %lld rest(split,final flush) %lld total %lld rows %d splits %d\n",
+           (int)blockIdx.x, t2[0], t2[1], t2[2], t2[3], t2[4], t2[5], wall_clock64() - t2start, nrows_done, nsplit);
+#endif
   const double dn = dnorm[w];
   for (int k = tid; k < num; k += blockDim.x) {
     periods_io[w * num + k] = periods[k];
