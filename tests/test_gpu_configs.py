@@ -136,6 +136,21 @@ def test_config3_ramanujan_batch(eng, golden):
     assert len(others) >= 10 and r[others].max() < 1e-18 * r[divs].max()
 
 
+def test_ramanujan_without_the_pad_behind_the_window(eng):
+    """Shapes where dropping the zeroed pad behind the LDS window makes room for one more wavefront (N = 5000 fp64 with
+    q <= 640: 15 wavefronts with the pad, 16 without; config 3 is the other such shape): a fold then reads past the window
+    into the strips for lanes whose sums it discards.  Odd batch, a ragged length, q_lo = 1 (slot 0 of the output row is
+    the root queue and must come back as zero), every period against the fp64 folded oracle."""
+    x = multi_sinusoid_batch(77, 3, 5000)
+    out = eng.ramanujan_norms(x, 1, 640)
+    assert out.shape == (3, 641) and not out[:, 0].any()
+    for w in (0, 2):
+        want = po.ramanujan_norms_folded(x[w], 1, 640)
+        assert rel_err(out[w], want) < TOL and elem_err(out[w], want) < 1e-9
+    again = eng.ramanujan_norms(x[1:2], 1, 640)
+    assert np.array_equal(again[0], out[1])  # batch == per-window, and the queue slot was reset
+
+
 def test_ramanujan_default_range(eng, golden):
     """RamanujanPeriods().find_periods(x) with the reference's default max_length = len(x) // 3
     (RamanujanPeriods.py:68-69) at N = 4096 .. 16384: the per-wavefront strips are sized by the range."""
