@@ -220,7 +220,8 @@ int ph_dict_project(ph_ctx* ctx, const double* x, const double* basis, int rows,
  * (QOPeriods.py:373-596, get_subspaces :830-840, solve_quadratic :779-796) with the default
  * test function rms(reconstruction) > rms(data) * thresh.  The whole greedy loop runs on the
  * device, one workgroup per window: gamma sweep, phi-mass row bookkeeping, Gram matrix (closed-form
- * counts) and right-hand side by folds, bordered blocked Cholesky solve, reconstruction, residual.
+ * counts, never formed: regenerated inside the product) and right-hand side by folds, matrix-free preconditioned
+ * conjugate-gradient solve of A A^T w = A x, reconstruction, residual.
  * Any N (the residual moves to an HBM workspace when it does not fit the LDS beside the solver).
  * periods/norms/keeps (W, num): dictionary blocks in the order found (period, gamma norm, rows
  * kept); counts (W, 2) = {periods the reference reports, blocks in the dictionary} (they differ
@@ -233,8 +234,8 @@ int ph_qo_find_periods(ph_ctx* ctx, const void* x, int dtype, int64_t W, int N, 
                        double* weights, void* residual, int32_t* status);
 
 /* *ok = 1 when ph_qo_find_periods can run windows of N samples of `dtype` with `kcap` dictionary
- * rows on this device (window, solve vector and at least one Cholesky panel column fit the
- * workgroup's LDS), else 0 -- callers fall back to a host-driven loop instead of catching PH_E_ARG. */
+ * rows on this device (bookkeeping and the six work vectors of the conjugate-gradient solve fit the
+ * workgroup's LDS; the window joins them there or moves to the HBM workspace), else 0 -- callers fall back to a host-driven loop instead of catching PH_E_ARG. */
 int ph_qo_feasible(ph_ctx* ctx, int dtype, int N, int max_length, int kcap, int* ok);
 
 /* ---- QOPeriods.get_best_period_orthogonal / eq_3 / auto_corr (QOPeriods.py:1122-1232) -----

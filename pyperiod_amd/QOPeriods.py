@@ -5,7 +5,7 @@ even be constructed (QOPeriods.py:190) and only its non-orthogonal ``find_period
 (SURVEY.md section 0); that branch is what is implemented here:
 
   * plain projection, default test function: the whole greedy loop (gamma sweep, phi-mass row
-    bookkeeping, Gram matrix and right-hand side by folds, Cholesky solve, reconstruction,
+    bookkeeping, right-hand side by folds, matrix-free conjugate-gradient solve, reconstruction,
     residual) runs in ONE kernel launch per window batch -> ph_qo_find_periods
   * other settings (custom test_function, update_weights=False, trunc, window, Ramanujan basis):
     the loop is driven from the host with the heavy pieces on the GPU -- the sweep (ph_sweep,

@@ -1333,7 +1333,6 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   int* cb = cv.take<int>(6);  // first flagged period of this round per window: three parities x two windows
 
   const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const size_t gstride = win_stride((size_t)N);

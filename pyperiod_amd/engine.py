@@ -366,7 +366,7 @@ class PeriodEngine:
 
     def qo_feasible(self, n, dtype=np.float64, kcap=512, max_length=None) -> bool:
         """Whether ph_qo_find_periods can run a window of n samples with `kcap` dictionary rows
-        (window + solve vector + one Cholesky panel column must fit the workgroup's LDS)."""
+        (bookkeeping + the work vectors of the conjugate-gradient solve must fit the workgroup's LDS)."""
         ok = C.c_int(0)
         code = _NP_DTYPES[np.dtype(dtype)]
         _ffi.check(self._lib.ph_qo_feasible(self._ctx, code, int(n), int(max_length if max_length is not None else n // 3),

@@ -18,19 +18,25 @@ def pytest_configure(config):
 _DIST_JOB = {}
 
 
-def pytest_sessionstart(session):
-    """The 2-rank sharding job of tests/test_gpu_dist.py runs as a child process tree that must be started BEFORE this
-    process touches the GPU (a process that has initialised HIP must not fork+exec on the GPU boxes): start it
-    here, while GPU tests are selected and a device is visible; the test collects it."""
-    expr = session.config.getoption("-m") or ""
-    if "gpu" not in expr or "not gpu" in expr:
-        return
-    try:
-        import torch
+def _gpu_visible():
+    """Is there a GPU, decided WITHOUT the HIP runtime (torch.cuda.device_count() may fall through to
+    hipGetDeviceCount, which initialises it): the kernel driver's device node and the visibility variables."""
+    if not os.path.exists("/dev/kfd"):
+        return False
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, None) in ("", "-1"):
+            return False
+    return True
 
-        if torch.cuda.device_count() < 1:  # does not initialise the GPU
-            return
-    except Exception:  # noqa: BLE001
+
+def pytest_collection_finish(session):
+    """The 2-rank sharding job of tests/test_gpu_dist.py runs as a child process tree that must be started BEFORE this
+    process touches the GPU (a process that has initialised HIP must not fork+exec on the GPU boxes).  Collection
+    imports the test modules but runs nothing, so this hook -- after deselection (-m, -k), before the first test --
+    starts it, and only when the test that reads its result is among the selected items."""
+    if "proc" in _DIST_JOB or not _gpu_visible():
+        return
+    if not any(it.nodeid.endswith("test_gpu_dist.py::test_two_ranks_hip_engine_equal_single_process") for it in session.items):
         return
     import subprocess
     import tempfile
@@ -41,15 +47,29 @@ def pytest_sessionstart(session):
 
 
 def pytest_sessionfinish(session, exitstatus):
+    """The launcher has its own 600 s deadline and kills its ranks; a session that ends early (failure with -x,
+    interrupt) must not leave them holding the GPU: terminate the launcher (it is our own child, exact PID) and,
+    if it does not go, kill it."""
     proc = _DIST_JOB.get("proc")
-    if proc is not None and proc.poll() is None:
-        proc.wait(timeout=900)
+    if proc is None or proc.poll() is not None:
+        return
+    import subprocess
+
+    try:
+        proc.wait(timeout=5 if exitstatus else 660)
+    except subprocess.TimeoutExpired:
+        proc.terminate()
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait()
 
 
 @pytest.fixture(scope="session")
 def dist_gpu_job():
     if "proc" not in _DIST_JOB:
-        pytest.skip("no GPU visible at session start")
+        pytest.skip("no GPU visible when the tests were collected")
     return _DIST_JOB["proc"], _DIST_JOB["out"]
 
 

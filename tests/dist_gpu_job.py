@@ -29,7 +29,11 @@ def launch(out_path):
     deadline = time.time() + 600
     rc = 0
     live = list(procs)
-    while live and not rc and time.time() < deadline:
+    stop = []
+    import signal
+
+    signal.signal(signal.SIGTERM, lambda *_: stop.append(1))  # the session ended early: end the ranks, then leave
+    while live and not rc and not stop and time.time() < deadline:
         time.sleep(0.2)
         for p in list(live):
             if p.poll() is not None:

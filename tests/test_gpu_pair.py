@@ -285,3 +285,104 @@ def test_best_correlation_pair_kernel_equals_one_window_kernel():
     finally:
         single.close()
         pair.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Chip-filling batches (VERDICT r3 "weak" 1): the pair kernels put windows (w, w+1) into one workgroup, keep two workgroups
+# per CU in step with wavefront priorities and take passes from an LDS queue -- behaviour that only shows when the grid
+# fills the chip.  Full config-2 batches (1024 and 1023 windows x 4096: the odd one ends with a lone window) through the
+# pair engine and the one-window engine, every window compared; the oracle on three of them.
+# ------------------------------------------------------------------------------------------------------------------
+def _two_engines(var):
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import PeriodEngine
+
+    old = os.environ.get(var)
+    os.environ[var] = "0"
+    single = PeriodEngine(0)
+    os.environ[var] = "1"
+    pair = PeriodEngine(0)
+    if old is None:
+        del os.environ[var]
+    else:
+        os.environ[var] = old
+    return single, pair
+
+
+def test_full_batch_m_best_gamma_pair_equals_one_window_kernel():
+    """m_best_gamma(10) (Periods.py:432-454), 1024 x 4096 and 1023 x 4096."""
+    import torch
+
+    single, pair = _two_engines("PH_STEP1_PAIR")
+    try:
+        assert pair.m_best_info(4096, 10) == (2, 8) and single.m_best_info(4096, 10) == (1, 8)
+        xh = multi_sinusoid_batch(0, 1024, 4096)
+        x = torch.from_numpy(xh).cuda()
+        for W in (1024, 1023):
+            a = [t.cpu().numpy() for t in single.m_best(x[:W], 10, gamma=True, want_sweeps=True)]
+            b = [t.cpu().numpy() for t in pair.m_best(x[:W], 10, gamma=True, want_sweeps=True)]
+            assert np.array_equal(a[0], b[0]), np.nonzero((a[0] != b[0]).any(1))[0][:10]  # periods, every window
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])  # status, sweeps
+            assert rel_err(b[1], a[1]) < 1e-13
+            for w in range(0, W, 97):  # bases of a sample of windows, each against its own scale
+                assert rel_err(b[2][w], a[2][w]) < 1e-13, w
+            del a
+            if W == 1023:
+                for w in (0, 511, 1022):  # first, middle, the lone window of the last workgroup
+                    want = po.m_best(xh[w], 10, gamma=True)
+                    assert np.array_equal(b[0][w].astype(np.int64), np.asarray(want[0]).astype(np.int64)), w
+                    assert rel_err(b[1][w], want[1]) < TOL and rel_err(b[2][w], want[2]) < TOL
+            del b
+    finally:
+        single.close()
+        pair.close()
+
+
+def test_full_batch_best_correlation_pair_equals_one_window_kernel():
+    """best_correlation(3) (Periods.py:289-349), 1024 x 4096 and 1023 x 4096."""
+    import torch
+
+    single, pair = _two_engines("PH_BC_PAIR")
+    try:
+        xh = multi_sinusoid_batch(0, 1024, 4096)
+        x = torch.from_numpy(xh).cuda()
+        for W in (1024, 1023):
+            a = [t.cpu().numpy() for t in single.best_correlation(x[:W], 3)]
+            b = [t.cpu().numpy() for t in pair.best_correlation(x[:W], 3)]
+            assert np.array_equal(a[0], b[0]), np.nonzero((a[0] != b[0]).any(1))[0][:10]
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])  # bases bit for bit (row-order projections), status
+            assert rel_err(b[1], a[1]) < 1e-13
+            if W == 1023:
+                for w in (0, 511, 1022):
+                    want = po.best_correlation(xh[w], 3)
+                    assert np.array_equal(b[0][w].astype(np.int64), np.asarray(want[0]).astype(np.int64)), w
+                    assert rel_err(b[1][w], want[1]) < TOL and rel_err(b[2][w], want[2]) < TOL
+    finally:
+        single.close()
+        pair.close()
+
+
+def test_shard_small_to_large_pair_equals_one_window_kernel():
+    """small_to_large(0.05) (Periods.py:246-287) on a config-4 shard, 8192 x 4096 (and 8191: a lone last window): counts,
+    periods, powers, status of every window bit for bit; the oracle on three windows."""
+    import torch
+
+    single, pair = _two_engines("PH_S2L_PAIR")
+    try:
+        xh = multi_sinusoid_batch(0, 8192, 4096)
+        x = torch.from_numpy(xh).cuda()
+        for W in (8192, 8191):
+            a = single.small_to_large(x[:W], 0.05, None, cap=32, want_bases=False)
+            b = pair.small_to_large(x[:W], 0.05, None, cap=32, want_bases=False)
+            for k in (0, 1, 2, 4):
+                assert torch.equal(a[k], b[k]), k
+        cnt, per, pw = b[0].cpu().numpy(), b[1].cpu().numpy(), b[2].cpu().numpy()
+        for w in (0, 4097, 8190):
+            want = po.small_to_large(xh[w], 0.05)
+            k = int(cnt[w])
+            assert list(per[w][:k]) == list(want[0]) and rel_err(pw[w][:k], np.array(want[1])) < TOL
+    finally:
+        single.close()
+        pair.close()
