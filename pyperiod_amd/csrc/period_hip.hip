@@ -70,6 +70,7 @@ struct ph_ctx {
   // per-period fold geometry for the tuned sweeps, cached for the last (N, max_p)
   DevBuf geom;
   DevBuf geomf;  // the same table in float (ph::PGeomF), for the window-pair screen
+  DevBuf kapf;   // kappa_q of k_small_to_large_pair's flag test (ph::s2l_kappa, rounded up to float)
   int geom_n = -1, geom_max_p = -1;
   bool step1_pair = true;  // PH_STEP1_PAIR=0: always the one-window fp64 kernel for m_best step 1
   bool s2l_pair = true;    // PH_S2L_PAIR=0: always the one-window kernel for small_to_large
@@ -85,6 +86,7 @@ struct ph_ctx {
   int sweep_block = ph::kBlockWide;  // threads per workgroup of the sweep kernels (PH_SWEEP_BLOCK overrides)
   int step1_block = 0;               // k_mbest_step1 only: 0 = automatic (PH_STEP1_BLOCK overrides, <= 1024)
   int qo_block = 1024;               // k_qo_find threads per workgroup (PH_QO_BLOCK overrides)
+  int s2l_block = 1024;              // k_small_to_large_pair threads per workgroup (PH_S2L_BLOCK overrides, >= 512)
   bool qo_hbm_window = false;        // PH_QO_HBM_WINDOW=1: keep the residual of k_qo_find in HBM even when it fits LDS
   // optional per-kernel HIP-event timing (ph_profile_*)
   bool prof_on = false;
@@ -246,6 +248,15 @@ int prepare_geom(ph_ctx* c, int N, int max_p, const ph::PGeom** out) {
     hostf[p] = ph::PGeomF{host[p].rows, host[p].nfull, (float)host[p].w_full, (float)host[p].w_short};
   PH_TRY(ensure(c, c->geomf, hostf.size() * sizeof(ph::PGeomF)));
   PH_HIP(hipMemcpyAsync(c->geomf.p, hostf.data(), hostf.size() * sizeof(ph::PGeomF), hipMemcpyHostToDevice, c->stream));
+  std::vector<float> hostk(host.size(), 0.0f);
+  for (size_t p = 1; p < host.size(); ++p) {
+    const double k = ph::s2l_kappa(N, host[p].rows, (int)p);
+    float f = (float)k;
+    if ((double)f < k) f = std::nextafterf(f, INFINITY);
+    hostk[p] = f;
+  }
+  PH_TRY(ensure(c, c->kapf, hostk.size() * sizeof(float)));
+  PH_HIP(hipMemcpyAsync(c->kapf.p, hostk.data(), hostk.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   PH_HIP(hipStreamSynchronize(c->stream));
   c->geom_n = N;
   c->geom_max_p = max_p;
@@ -487,6 +498,15 @@ extern "C" {
 
 int ph_version(void) { return PH_VERSION; }
 
+#ifdef PH_CLOCKS
+// diagnostic builds only (not part of the C ABI): workgroup stamps of the last k_small_to_large_pair launch
+int ph_debug_stamps(long long* dst, int n_wg) {
+  PH_HIP(hipDeviceSynchronize());
+  PH_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_ph_stamps), sizeof(long long) * 4 * (size_t)n_wg));
+  return PH_OK;
+}
+#endif
+
 const char* ph_last_error(void) { return g_err.c_str(); }
 
 int ph_device_count(int* count) {
@@ -542,6 +562,10 @@ int ph_create(int device, ph_ctx** out) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->step1_block = v;
   }
+  if (const char* e = std::getenv("PH_S2L_BLOCK")) {
+    const int v = std::atoi(e);
+    if (v >= 512 && v <= 1024 && v % 64 == 0) c->s2l_block = v;
+  }
   if (const char* e = std::getenv("PH_QO_BLOCK")) {
     const int v = std::atoi(e);
     if (v >= 64 && v <= 1024 && v % 64 == 0) c->qo_block = v;
@@ -565,6 +589,7 @@ int ph_destroy(ph_ctx* c) {
     if (t.dev.p) (void)hipFree(t.dev.p);
   if (c->geom.p) (void)hipFree(c->geom.p);
   if (c->geomf.p) (void)hipFree(c->geomf.p);
+  if (c->kapf.p) (void)hipFree(c->kapf.p);
   if (c->plan.p) (void)hipFree(c->plan.p);
   if (c->twid.p) (void)hipFree(c->twid.p);
   if (c->bs_tab.p) (void)hipFree(c->bs_tab.p);
@@ -904,7 +929,7 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   const bool general = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
-  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) +
+  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : carve_bytes(kBlockWide, sz)) + carve_bytes(kRedDoubles, 8) +
                carve_bytes(ph::kS2LBatch, 8) + carve_bytes(4, 4);
   void* gbuf;
   PH_TRY(place_second_buffer(c, &lds, general, (size_t)N * sz, W, &gbuf));
@@ -928,25 +953,29 @@ int ph_small_to_large(ph_ctx* c, const void* x, int dtype, int64_t W, int N, dou
   PH_HIP(hipMemsetAsync(dpow, 0, (size_t)W * cap * sizeof(double), c->stream));
   PH_TRY(ensure(c, c->buf[B_GEN0], 256));
   int* dmax = static_cast<int*>(c->buf[B_GEN0].p);  // largest count of the batch (device word)
-  PH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), c->stream));
+  PH_HIP(hipMemsetAsync(dmax, 0, 2 * sizeof(int), c->stream));  // [1]: pair counter of the persistent pair kernel
   const unsigned kflags = flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH);
   const dim3 grid((unsigned)W);
-  // Window-pair screen (k_small_to_large_pair): fp64 windows, plain projection, candidate periods below N.  Its LDS
-  // is the pair window alone; the fp64 residuals live in an HBM workspace.
-  const size_t lds_pair = carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(ph::kS2LBatch, 8) +
-                          carve_bytes(14, 8) + carve_bytes(8, 4) + carve_bytes(6, 4);
-  const bool pair = c->s2l_pair && dtype == PH_F64 && !general && !gwin && n_periods < N && c->sweep_block >= 512 &&
-                    lds_pair <= (size_t)c->lds_limit;
+  // Window-pair screen (ph_s2l.h): fp64 windows, plain projection, candidate periods below N.  LDS: the pair window and
+  // one fp64 staging buffer, two 16-wave workgroups per CU; the fp64 residuals live in an HBM workspace.
+  const size_t lds_pair = ph::s2l_pair_lds_bytes(N);
+  const bool pair_ok = c->s2l_pair && dtype == PH_F64 && !general && !gwin && n_periods < N && n_periods >= 2 &&
+                       c->sweep_block >= 512;
+  const bool pair = pair_ok && lds_pair <= (size_t)c->lds_limit;
   if (pair) {
     const size_t gstride = ph::win_stride((size_t)N);
     PH_TRY(ensure(c, c->buf[B_GWIN], (size_t)W * gstride * sizeof(double)));
     auto kernel = ph::k_small_to_large_pair;
     PH_TRY(allow_lds(kernel, lds_pair));
     ProfScope ps_(c, "k_small_to_large");
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((W + 1) / 2)), dim3(c->sweep_block), lds_pair, c->stream, (const double*)dx,
-                       (int)W, N, thresh, n_periods, static_cast<const ph::PGeomF*>(c->geomf.p),
+    // persistent workgroups: as many as are resident at once (LDS and the 32 wavefronts of a CU), pairs from a counter
+    const int64_t npairs = (W + 1) / 2;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->lds_limit / lds_pair, 2048 / (size_t)c->s2l_block));
+    const unsigned grid_pairs = (unsigned)std::min<int64_t>(npairs, (int64_t)c->num_cu * per_cu);
+    hipLaunchKernelGGL(kernel, dim3(grid_pairs), dim3(c->s2l_block), lds_pair, c->stream, (const double*)dx, (int)W, N,
+                       thresh, n_periods, static_cast<const ph::PGeomF*>(c->geomf.p), static_cast<const float*>(c->kapf.p),
                        static_cast<double*>(c->buf[B_GWIN].p), cap, (int*)dcnt, (int*)dper, (double*)dpow, (double*)dbases,
-                       (int*)dstat, dmax);
+                       (int*)dstat, dmax, dmax + 1);
   } else
   PH_TRY(dispatch(dtype, !gwin, [&](auto t, auto lw) {
     using T = decltype(t);

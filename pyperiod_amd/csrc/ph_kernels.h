@@ -1137,6 +1137,74 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // on the config-4 shard) and 16 / 24 / 48.
 constexpr int kS2LBatch = 32;
 
+// Exact evaluation of a candidate period p <= kBlockWide (Periods.py:274-281), shared by the one-window and the
+// window-pair kernel so that both sum in the same order.  A short period has few residues with hundreds of rows each:
+// one thread per residue walking its column (the order of Periods.project) left all but p threads idle behind a chain
+// of N/p dependent additions -- 3 us per event, a quarter of the kernel.  Here the rows of a residue are dealt to
+// G = 2^k <= width / p threads (thread (g, j) adds rows g, g + G, ... in order), the G partial sums are combined in
+// order of g, and the trial residual's sum of squares and the update run FLAT over the samples (thread t takes
+// n = t, t + width, ... with the mean index kept incrementally).  The mean of a residue is then a differently
+// associated sum than np.sum(cp, 0) (Periods.py:194) -- within 1e-15 of it; small_to_large's bases and powers carry a
+// 1e-10 bar, only Periods.project itself (ph_project_batch) is held to bit-identity -- and np.linalg.norm has no
+// defined order anyway.  Threads >= width do nothing; msm holds >= width elements.
+template <typename T>
+__device__ __forceinline__ double s2l_flat_trial(const T* __restrict__ work, T* __restrict__ msm, int N, int p, int tid, int width) {
+  const Fold f(N, p);
+  int G = 1;
+  while (2 * G * p <= width && G < 64) G <<= 1;
+  if (G == 1) {
+    if (tid < width)
+      for (int j = tid; j < p; j += width) msm[j] = residue_mean(work, f, j, false);
+  } else {
+    const int g = tid / p, j = tid - g * p;  // g < G for the threads that take part
+    if (tid < G * p) {
+      const int cnt = f.count(j);
+      const int n = cnt > g ? (cnt - g + G - 1) / G : 0;  // rows g, g + G, ... below cnt
+      msm[tid] = column_sum(work + (size_t)g * p, j, G * p, n);
+    }
+    __syncthreads();
+    T s = T(0);
+    if (tid < p) {
+      s = msm[tid];
+      for (int k = 1; k < G; ++k) s += msm[k * p + tid];
+    }
+    __syncthreads();  // every partial has been read: the first p slots now take the means
+    if (tid < p) msm[tid] = s / T(f.count(tid));
+  }
+  __syncthreads();
+  double tsq = 0.0;
+  if (tid < width) {
+    int idx = tid % p;
+    const int step = width % p;
+    for (int n = tid; n < N; n += width) {
+      const double t = (double)(work[n] - msm[idx]);
+      tsq = fma(t, t, tsq);
+      idx += step;
+      idx = idx >= p ? idx - p : idx;
+    }
+  }
+  return tsq;
+}
+
+// residual <- residual - projection for the means in `msm`; brow (optional) receives the projection, extra(n, v) sees
+// every new residual sample
+template <typename T, typename F>
+__device__ __forceinline__ void s2l_flat_update(T* __restrict__ work, const T* __restrict__ msm, int N, int p, int tid, int width,
+                                                T* __restrict__ brow, F&& extra) {
+  if (tid >= width) return;
+  int idx = tid % p;
+  const int step = width % p;
+  for (int n = tid; n < N; n += width) {
+    const T m = msm[idx];
+    const T v = work[n] - m;
+    if (brow) brow[n] = m;
+    work[n] = v;
+    extra(n, v);
+    idx += step;
+    idx = idx >= p ? idx - p : idx;
+  }
+}
+
 template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
                                                            int n_periods, unsigned flags, Tables tb,
@@ -1154,6 +1222,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   double* red = cv.take<double>(kRedDoubles);
   double* psq = cv.take<double>(kS2LBatch);
   int* cand_slot = cv.take<int>(4);
+  T* msm = general ? nullptr : cv.take<T>(kBlockWide);  // means of a candidate period <= kBlockWide (s2l_flat_* below)
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1233,7 +1302,10 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     }
     // exact evaluation (row-order means, direct sum of squares of the trial residual)
     double tsq = 0.0;
-    if (!general) {
+    const bool flat = !general && cand <= kBlockWide;
+    if (flat) {
+      tsq = s2l_flat_trial(work, msm, N, cand, tid, (int)blockDim.x);
+    } else if (!general) {
       const Fold f(N, cand);
       for (int j = tid; j < cand; j += blockDim.x) {
         const T m = residue_mean(work, f, j, false);
@@ -1256,7 +1328,9 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     const double imposed = uniform_f64((rn - tn) / dn);
     if (imposed > thresh) {  // strict, Periods.py:281
       T* brow = (bases_out && count < cap) ? bases_out + (w * cap + count) * (int64_t)N : nullptr;
-      if (!general) {
+      if (flat) {
+        s2l_flat_update(work, msm, N, cand, tid, (int)blockDim.x, brow, [](int, T) {});
+      } else if (!general) {
         const Fold f(N, cand);
         for (int j = tid; j < cand; j += blockDim.x) {
           const T m = residue_mean(work, f, j, false);
@@ -1296,258 +1370,9 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   }
 }
 
-// ======================================================================================
-// Periods.small_to_large, window-pair screen (plain projection, fp64 windows).
-//   Two windows per workgroup share the pair window of ph_pair.h: the ascending screen of k_small_to_large
-//   (||r||^2 - ||P_q r||^2 as an estimate of the reference's norm drop, Periods.py:274-281) runs on the float
-//   images of both -- one pass of the wave-per-period fold per candidate period for the two windows.  The fp64
-//   residuals live in an HBM workspace (the input itself until a window accepts its first period); a period whose
-//   estimate, widened by the rigorous float radius (pair_radius) and the fp64 terms of k_small_to_large's bound,
-//   reaches the threshold is evaluated exactly from there (row-order means, direct sum of squares of the trial
-//   residual), so accept decisions, powers and bases are those of the one-window kernel.
-//   The two windows walk the period range together: a batch starts at the smaller of their positions, and a
-//   window ignores screen values below its own position (it re-screens what its partner still has to decide).
-//   LDS: 35 KB per pair at N = 4096 -> four workgroups of eight wavefronts per CU, i.e. eight windows per CU.
-// ======================================================================================
-// float image of window w of a pair times a power of two (its scale is renewed when the residual has collapsed)
-__device__ __forceinline__ void s2l_pair_rescale(float* __restrict__ pwf, int w, int N, float up) {
-  for (int n = threadIdx.x; n < N; n += blockDim.x) pwf[2 * n + w] *= up;
-}
-
-__global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large_pair(
-    const double* __restrict__ x, int W, int N, double thresh, int n_periods, const PGeomF* __restrict__ geomf,
-    double* __restrict__ gres, int cap, int* __restrict__ counts, int* __restrict__ periods_out,
-    double* __restrict__ powers_out, double* __restrict__ bases_out, int* __restrict__ status_out,
-    int* __restrict__ max_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Carve cv(smem);
-  f2* pw = cv.take<f2>(N + kPad);
-  double* red = cv.take<double>(kRedDoubles);
-  f2* psq = cv.take<f2>(kS2LBatch);
-  // per window w: st[w] ||residual||^2, st[2+w] periodic_norm(residual), st[4+w] periodic_norm(data), st[6+w] scale of
-  // the float image, st[8+w], st[10+w], st[12+w]: A, rsq / A, 1 / scale^2 of the flag test below; ct[w] first period
-  // (start of the walk), ct[2+w] periods accepted, ct[6+w] 1 once a period was accepted (the residual then lives in
-  // the workspace).  The positions of the two windows are kept in registers, identical in every thread.
-  double* st = cv.take<double>(14);
-  int* ct = cv.take<int>(8);
-  int* cb = cv.take<int>(6);  // first flagged period of this round per window: three parities x two windows
-
-  const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = blockDim.x >> 6;
-  const size_t gstride = win_stride((size_t)N);
-  float* pwf = reinterpret_cast<float*>(pw);
-  const double sqrtN = uniform_f64(sqrt((double)N));
-  for (int i = tid; i < kPad; i += blockDim.x) pw[N + i] = f2_zero();
-  for (int w = 0; w < 2; ++w) {
-    const int64_t gw = 2 * (int64_t)blockIdx.x + w;
-    const bool exists = gw < W;
-    const double* src = x + gw * (int64_t)N;
-    double acc = 0.0;
-    if (exists)
-      for (int n = tid; n < N; n += blockDim.x) {
-        const double v = src[n];
-        acc = fma(v, v, acc);
-      }
-    const double rsq = block_sum(acc, red);
-    const double sc = uniform_f64(pair_pick_scale(rsq, N));
-    for (int n = tid; n < N; n += blockDim.x) pwf[2 * n + w] = exists ? (float)(src[n] * sc) : 0.0f;
-    if (tid == 0) {
-      const double dnorm = sqrt(rsq) / sqrtN;  // data_norm, Periods.py:269
-      st[w] = rsq;
-      st[2 + w] = st[4 + w] = dnorm;
-      st[6 + w] = sc;
-      const double A = (dnorm - (thresh - 1e-13) * dnorm) * sqrtN;
-      st[8 + w] = A;
-      st[10 + w] = rsq / A;
-      st[12 + w] = 1.0 / (sc * sc);
-      ct[w] = exists ? 2 : n_periods + 1;
-      ct[2 + w] = 0;
-      ct[6 + w] = 0;
-    }
-  }
-  if (tid < 6) cb[tid] = 0x7fffffff;
-  __syncthreads();
-  // Positions of the two windows: identical in every thread (they only change with values all threads read).
-  int pos0 = ct[0], pos1 = ct[1];
-#ifdef PH_S2L_TIMERS
-  long long tp[4] = {0, 0, 0, 0};
-  long long tp0 = wall_clock64();
-  int nev = 0, nrounds = 0;
-#define PH_S2LP_MARK(k)                    \
-  {                                        \
-    const long long now_ = wall_clock64(); \
-    tp[k] += now_ - tp0;                   \
-    tp0 = now_;                            \
-  }
-#else
-#define PH_S2LP_MARK(k)
-#endif
-
-  for (int round = 0;; ++round) {
-    const int p = min(pos0, pos1);
-    if (p > n_periods) break;
-    const int hi = min(n_periods, p + kS2LBatch - 1);
-    int* cbr = cb + 2 * (round % 3);
-    if (tid < 2) cb[2 * ((round + 1) % 3) + tid] = 0x7fffffff;  // next round's slots (last read two barriers ago)
-    prio_long_phase();  // the events below wait on L2 round trips and run ahead of the other workgroups' screens (-1.6 %)
-    // ---- screen [p, hi] on the float images of both windows
-    for (int q = p + wv; q <= hi; q += nw) {
-      f2 part[3];
-      f2 v;
-      if (q >= 64) {
-        pair_pass_seg<1>(pw, q, geomf, part);
-        v = pair_wave_sum(part[0]);
-      } else {
-        v = pair_wave_sum(pair_partial_small(pw, N, q, geomf[q]));
-      }
-      if (pair_lane() == 0) psq[q - p] = v;
-    }
-    // ---- which of this wavefront's periods has to be evaluated exactly?  Lane k < 4 looks at the wave's k-th period for
-    //      window 0, lane 4 + k for window 1 (a wave reads back only what it wrote).  Decision bound of
-    //      k_small_to_large with the float radius in place of the fp64 one: the screen has t_s = rsq - psq, the decision
-    //      is taken on t_e = fl(sum (r - m)^2), |t_s - t_e| <= D = kappa rsq.  With t = sqrt(t_s), the test
-    //      est + err > thresh for est = (rn - t / sqrtN) / dn, err <= D / (t sqrtN dn) + 1e-13 reads t - D / t < A,
-    //      A = (rn - (thresh - 1e-13) dn) sqrtN, which holds only below t* = (A + sqrt(A^2 + 4 D)) / 2 <= A + D / A:
-    //      flag unless rsq - psq >= (A + kappa rsq / A)^2 -- no square root, no division per period.
-    {
-      const int l = pair_lane();
-      const int w = (l >> 2) & 1;
-      const int q = p + wv + (l & 3) * nw;
-      bool flag = false;
-      if (l < 8 && q <= hi && q >= (w ? pos1 : pos0)) {
-        const f2 v = psq[q - p];
-        const double rsq = st[w], A = st[8 + w], c = st[10 + w];
-        const double ps = (double)(w ? v.y : v.x) * st[12 + w];
-        const double kappa = pair_radius(geomf[q].rows, q) * (1.0 + 1e-9) + ((double)N / 256.0 + 32.0) * 2.220446049250313e-16;
-        // upper bound of t*^2: (A + D / A)^2 for A > 0; for A <= 0 (the residual is already below thresh x data: nothing
-        // can be accepted except through the error term) t* <= min(sqrt(D), D / |A|)
-        const double kc = kappa * c, ts = A + kc;
-        const double lim = A > 0.0 ? ts * ts : fmin(kappa * rsq, kc * kc);
-        flag = !(rsq - ps >= lim * (1.0 + 1e-12));  // NaN -> evaluate
-      }
-      const unsigned long long mask = __ballot(flag);
-      if (l < 2) {
-        const unsigned m = (unsigned)(mask >> (4 * l)) & 0xFu;
-        if (m) atomicMin(&cbr[l], p + wv + (__ffs((int)m) - 1) * nw);
-      }
-    }
-    __syncthreads();
-    PH_S2LP_MARK(0)
-#ifdef PH_S2L_TIMERS
-    nrounds += 1;
-#endif
-    const int c0 = cbr[0], c1 = cbr[1];
-    if (c0 == 0x7fffffff && c1 == 0x7fffffff) {  // the usual round: nothing to evaluate, both windows move past the batch
-      pos0 = pos0 <= hi ? hi + 1 : pos0;
-      pos1 = pos1 <= hi ? hi + 1 : pos1;
-      continue;
-    }
-    prio_short_phase();
-    // ---- exact evaluation of each window's candidate (Periods.py:274-286) on its fp64 residual
-    for (int w = 0; w < 2; ++w) {
-      const int cand = w ? c1 : c0;
-      if (cand == 0x7fffffff) {  // no candidate: finished, ahead of this batch, or past it now
-        if (w ? pos1 <= hi : pos0 <= hi) (w ? pos1 : pos0) = hi + 1;
-        continue;
-      }
-      __syncthreads();
-      const int64_t gw = 2 * (int64_t)blockIdx.x + w;
-      const bool moved = ct[6 + w] != 0;
-      const double* res = moved ? gres + gw * gstride : x + gw * (int64_t)N;
-      const double rn = st[2 + w], dn = st[4 + w], sc = st[6 + w];
-      const int count = ct[2 + w];
-      const Fold f(N, cand);
-      double tsq = 0.0;
-      // cand <= blockDim: one column per thread -- its mean stays in a register for the update below (these are the
-      // long columns, read through L2; a second row-order sum of them costs as much as the first)
-      const bool one_col = cand <= (int)blockDim.x;
-      double m_own = 0.0;
-      if (one_col) {
-        if (tid < cand) {
-          m_own = residue_mean(res, f, tid, false);
-          const int cnt = f.count(tid);
-          for (int r = 0; r < cnt; ++r) {
-            const double t = res[r * cand + tid] - m_own;
-            tsq = fma(t, t, tsq);
-          }
-        }
-      } else {
-        for (int j = tid; j < cand; j += blockDim.x) {
-          const double m = residue_mean(res, f, j, false);
-          const int cnt = f.count(j);
-          for (int r = 0; r < cnt; ++r) {
-            const double t = res[r * cand + j] - m;
-            tsq = fma(t, t, tsq);
-          }
-        }
-      }
-      tsq = block_sum(tsq, red);
-      PH_S2LP_MARK(1)
-#ifdef PH_S2L_TIMERS
-      nev += 1;
-#endif
-      const double tn = uniform_f64(sqrt(tsq) / sqrtN);
-      const double imposed = uniform_f64((rn - tn) / dn);
-      if (imposed > thresh) {  // strict, Periods.py:281
-        double* brow = (bases_out && count < cap) ? bases_out + (gw * cap + count) * (int64_t)N : nullptr;
-        double* dst = gres + gw * gstride;
-        for (int j = tid; j < cand; j += blockDim.x) {
-          const double m = one_col ? m_own : residue_mean(res, f, j, false);
-          const int cnt = f.count(j);
-          for (int r = 0; r < cnt; ++r) {
-            const int n = r * cand + j;
-            const double v = res[n] - m;
-            if (brow) brow[n] = m;
-            dst[n] = v;
-            pwf[2 * n + w] = (float)(v * sc);
-          }
-        }
-        __threadfence_block();
-        __syncthreads();
-        double sc_now = sc;
-        if (pair_usable(tsq) && tsq * sc * sc < 9.0e-13 * (double)N) {  // float image below 2^-20 RMS: renew its scale
-          const double sc2 = uniform_f64(pair_pick_scale(tsq, N));
-          s2l_pair_rescale(pwf, w, N, (float)(sc2 / sc));
-          sc_now = sc2;
-        }
-        if (tid == 0) {
-          st[6 + w] = sc_now;
-          const double A = (tn - (thresh - 1e-13) * dn) * sqrtN;
-          st[8 + w] = A;
-          st[10 + w] = tsq / A;
-          st[12 + w] = 1.0 / (sc_now * sc_now);
-          if (count < cap) {
-            periods_out[gw * cap + count] = cand;
-            powers_out[gw * cap + count] = imposed;
-          }
-          ct[2 + w] = count + 1;
-          ct[6 + w] = 1;
-          st[w] = tsq;
-          st[2 + w] = tn;
-        }
-      }
-      (w ? pos1 : pos0) = cand + 1;
-      PH_S2LP_MARK(2)
-    }
-    __syncthreads();
-  }
-#ifdef PH_S2L_TIMERS
-  if (blockIdx.x < 6 && tid == 0)
-    printf("s2l pair timers (100 MHz ticks) screen %lld exact %lld update %lld  rounds %d events %d accepts %d %d\n", tp[0], tp[1],
-           tp[2], nrounds, nev, ct[2], ct[3]);
-#endif
-  __syncthreads();
-  if (tid < 2) {
-    const int64_t gw = 2 * (int64_t)blockIdx.x + tid;
-    if (gw < W) {
-      const int count = ct[2 + tid];
-      counts[gw] = count;
-      status_out[gw] = count > cap ? 3 : 0;
-      if (count > cap) atomicMax(max_count, count);  // rare: the host retries with this capacity
-    }
-  }
-}
+}  // namespace ph
+#include "ph_s2l.h"
+namespace ph {
 
 // ======================================================================================
 // Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.

@@ -32,9 +32,12 @@ for name, env in (("single", "0"), ("pair", "1")):
         print(f"{name:6s} thresh {thresh} bases {bases}: {np.mean(ks):.3f} ms ({xx.shape[0]} windows), accepted mean {res[(name, thresh)][0].mean():.2f}", flush=True)
     eng.close()
 for thresh in (0.05, 0.1):
-    a, b = res[("single", thresh)], res[("pair", thresh)]
-    ok = [np.array_equal(u, v) for u, v in zip(a, b) if u is not None]
-    print("thresh", thresh, "counts / periods / powers / (bases) / status identical:", ok)
+  for other in ("pair",):
+    a, b = res[("single", thresh)], res[(other, thresh)]
+    ok = [np.array_equal(u, v) for u, v in zip(a[:3] + a[4:], b[:3] + b[4:])]
+    if a[3] is not None:  # bases: the rows the kernels wrote
+        ok.append(all(np.array_equal(a[3][w, :k], b[3][w, :k]) for w, k in enumerate(a[0])))
+    print(other, "thresh", thresh, "counts / periods / powers / status / (bases) identical to the one-window kernel:", ok)
     if not all(ok):
         bad = np.nonzero(a[0] != b[0])[0]
         print("  windows with different counts:", bad[:10], a[0][bad[:5]], b[0][bad[:5]])
