@@ -243,11 +243,13 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the config-4 leg")
     ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 leg")
     ap.add_argument("--c4-windows", type=int, default=C4_WINDOWS, help="rehearsals only; the reported config is 65536")
-    ap.add_argument("--pieces", type=int, default=4, help="N>1: pieces the scatter of each rank's block is cut into")
+    ap.add_argument("--pieces", default="1,3", help="N>1: how the scatter of each rank's block is cut: a count of equal pieces "
+                    "or comma-separated weights (default 1,3: a quarter first, then the rest -- pyperiod_amd/dist.py piece_rows)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    pieces = int(args.pieces) if "," not in args.pieces else tuple(float(v) for v in args.pieces.split(","))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)  # does not return
@@ -537,7 +539,7 @@ def main():
             del x4_host
 
             def step4():
-                return run_sharded_pipelined(c4_compute, x_root, total, N_SAMPLES, torch.float64, dev, pieces=args.pieces)
+                return run_sharded_pipelined(c4_compute, x_root, total, N_SAMPLES, torch.float64, dev, pieces=pieces)
 
             res = step4()  # warm-up
             barrier()

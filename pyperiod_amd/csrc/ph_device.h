@@ -95,6 +95,21 @@ __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// red[0] + red[1] + ... + red[nw - 1] in that order, with all kMaxWaves reads in flight before the first addition
+// (a loop over the run-time wave count was compiled into nw dependent LDS round trips: ~1 us at 16 wavefronts).
+// Slots >= nw are read but not used; the result is the value of the plain loop, bit for bit.
+template <bool MAXOP = false>
+__device__ __forceinline__ double red_combine(const double* red, int nw) {
+  double v[kMaxWaves];
+#pragma unroll
+  for (int i = 0; i < kMaxWaves; ++i) v[i] = red[i];
+  double t = MAXOP ? v[0] : 0.0 + v[0];
+#pragma unroll
+  for (int i = 1; i < kMaxWaves; ++i)
+    if (i < nw) t = MAXOP ? fmax(t, v[i]) : t + v[i];
+  return t;
+}
+
 // Sum over the workgroup; every thread gets the result.  `red` holds >= 2*kMaxWaves doubles.
 // Partials are combined in wave order, so the result is identical in all threads.
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -103,10 +118,19 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
   if ((tid & (kWave - 1)) == 0) red[tid >> 6] = v;
   __syncthreads();
-  double t = 0.0;
-  for (int i = 0; i < nw; ++i) t += red[i];
+  const double t = red_combine(red, nw);
   __syncthreads();
   return uniform_f64(t);
+}
+
+// block_sum without the trailing barrier: `red` must not be written again before the workgroup's next barrier
+__device__ __forceinline__ double block_sum_once(double v, double* red) {
+  const int tid = threadIdx.x;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  v = wave_sum(v);
+  if ((tid & (kWave - 1)) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return uniform_f64(red_combine(red, nw));
 }
 
 // sums of two values over the workgroup with one pair of barriers (every thread gets both)
@@ -120,11 +144,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
     red[kMaxWaves + (tid >> 6)] = b;
   }
   __syncthreads();
-  double ta = 0.0, tb = 0.0;
-  for (int i = 0; i < nw; ++i) {
-    ta += red[i];
-    tb += red[kMaxWaves + i];
-  }
+  const double ta = red_combine(red, nw), tb = red_combine(red + kMaxWaves, nw);
   __syncthreads();
   a = uniform_f64(ta);
   b = uniform_f64(tb);
@@ -137,8 +157,7 @@ __device__ __forceinline__ double block_max(double v, double* red) {
   v = wave_max(v);
   if ((tid & (kWave - 1)) == 0) red[tid >> 6] = v;
   __syncthreads();
-  double t = red[0];
-  for (int i = 1; i < nw; ++i) t = fmax(t, red[i]);
+  const double t = red_combine<true>(red, nw);
   __syncthreads();
   return uniform_f64(t);
 }
@@ -583,7 +602,7 @@ __device__ __forceinline__ void seg_group(typename Win<T, LDS>::ptr ptr, int p, 
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    if (MASK) {  // last group of the segment: lanes past its end hold garbage
+    if (MASK && c == C - 1) {  // last group of the segment, holding exactly the chunks that are left: lanes past the end of the LAST one hold garbage
 #pragma unroll
       for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : 0.0;
     }
@@ -635,7 +654,7 @@ __device__ __forceinline__ void rows_group(typename Win<T, LDS>::ptr ptr, int p,
     double t = (double)v[0][c];
 #pragma unroll
     for (int r = 1; r < NR; ++r) t += (double)v[r][c];
-    if (MASK) t = (64 * c + lane < nvalid) ? t : 0.0;
+    if (MASK && c == C - 1) t = (64 * c + lane < nvalid) ? t : 0.0;  // a masked group is cut in its LAST chunk only
     part = fma(t, t, part);
   }
 }

@@ -1126,6 +1126,10 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
   }
 }
 
+}  // namespace ph
+#include "ph_s2l.h"  // flat exact evaluation (shared) and the window-pair kernel
+namespace ph {
+
 // ======================================================================================
 // Periods.small_to_large  (Periods.py:246-287).  Sequential in p; one workgroup per window.
 //   Plain projection: screen every p with ||r - P r||^2 = ||r||^2 - ||P r||^2 (one LDS pass),
@@ -1136,74 +1140,6 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
 // period are discarded, (batch - 1) / 2 of them per accept on average: 32 beats 64 (9.4 vs 9.9 ms
 // on the config-4 shard) and 16 / 24 / 48.
 constexpr int kS2LBatch = 32;
-
-// Exact evaluation of a candidate period p <= kBlockWide (Periods.py:274-281), shared by the one-window and the
-// window-pair kernel so that both sum in the same order.  A short period has few residues with hundreds of rows each:
-// one thread per residue walking its column (the order of Periods.project) left all but p threads idle behind a chain
-// of N/p dependent additions -- 3 us per event, a quarter of the kernel.  Here the rows of a residue are dealt to
-// G = 2^k <= width / p threads (thread (g, j) adds rows g, g + G, ... in order), the G partial sums are combined in
-// order of g, and the trial residual's sum of squares and the update run FLAT over the samples (thread t takes
-// n = t, t + width, ... with the mean index kept incrementally).  The mean of a residue is then a differently
-// associated sum than np.sum(cp, 0) (Periods.py:194) -- within 1e-15 of it; small_to_large's bases and powers carry a
-// 1e-10 bar, only Periods.project itself (ph_project_batch) is held to bit-identity -- and np.linalg.norm has no
-// defined order anyway.  Threads >= width do nothing; msm holds >= width elements.
-template <typename T>
-__device__ __forceinline__ double s2l_flat_trial(const T* __restrict__ work, T* __restrict__ msm, int N, int p, int tid, int width) {
-  const Fold f(N, p);
-  int G = 1;
-  while (2 * G * p <= width && G < 64) G <<= 1;
-  if (G == 1) {
-    if (tid < width)
-      for (int j = tid; j < p; j += width) msm[j] = residue_mean(work, f, j, false);
-  } else {
-    const int g = tid / p, j = tid - g * p;  // g < G for the threads that take part
-    if (tid < G * p) {
-      const int cnt = f.count(j);
-      const int n = cnt > g ? (cnt - g + G - 1) / G : 0;  // rows g, g + G, ... below cnt
-      msm[tid] = column_sum(work + (size_t)g * p, j, G * p, n);
-    }
-    __syncthreads();
-    T s = T(0);
-    if (tid < p) {
-      s = msm[tid];
-      for (int k = 1; k < G; ++k) s += msm[k * p + tid];
-    }
-    __syncthreads();  // every partial has been read: the first p slots now take the means
-    if (tid < p) msm[tid] = s / T(f.count(tid));
-  }
-  __syncthreads();
-  double tsq = 0.0;
-  if (tid < width) {
-    int idx = tid % p;
-    const int step = width % p;
-    for (int n = tid; n < N; n += width) {
-      const double t = (double)(work[n] - msm[idx]);
-      tsq = fma(t, t, tsq);
-      idx += step;
-      idx = idx >= p ? idx - p : idx;
-    }
-  }
-  return tsq;
-}
-
-// residual <- residual - projection for the means in `msm`; brow (optional) receives the projection, extra(n, v) sees
-// every new residual sample
-template <typename T, typename F>
-__device__ __forceinline__ void s2l_flat_update(T* __restrict__ work, const T* __restrict__ msm, int N, int p, int tid, int width,
-                                                T* __restrict__ brow, F&& extra) {
-  if (tid >= width) return;
-  int idx = tid % p;
-  const int step = width % p;
-  for (int n = tid; n < N; n += width) {
-    const T m = msm[idx];
-    const T v = work[n] - m;
-    if (brow) brow[n] = m;
-    work[n] = v;
-    extra(n, v);
-    idx += step;
-    idx = idx >= p ? idx - p : idx;
-  }
-}
 
 template <typename T, bool LW>
 __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_STEP1_WAVES, 8))) void k_small_to_large(const T* __restrict__ x, int N, double thresh,
@@ -1304,7 +1240,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     double tsq = 0.0;
     const bool flat = !general && cand <= kBlockWide;
     if (flat) {
-      tsq = s2l_flat_trial(work, msm, N, cand, tid, (int)blockDim.x);
+      tsq = s2l_flat_trial(work, msm, msm, N, cand, tid, (int)blockDim.x);
     } else if (!general) {
       const Fold f(N, cand);
       for (int j = tid; j < cand; j += blockDim.x) {
@@ -1369,10 +1305,6 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
     if (count > cap) atomicMax(max_count, count);  // rare: the host retries with this capacity
   }
 }
-
-}  // namespace ph
-#include "ph_s2l.h"
-namespace ph {
 
 // ======================================================================================
 // Periods.best_correlation  (Periods.py:289-349).  One workgroup per window.

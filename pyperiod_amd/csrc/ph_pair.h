@@ -75,7 +75,7 @@ __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid,
     f2 t = v[0][c];
 #pragma unroll
     for (int r = 1; r < NR; ++r) t += v[r][c];
-    if (MASK) t = (64 * c + lane < nvalid) ? t : f2_zero();
+    if (MASK && c == C - 1) t = (64 * c + lane < nvalid) ? t : f2_zero();  // a masked group is cut in its LAST chunk only
     part = f2_acc<MX>(part, t);
   }
 }
@@ -139,7 +139,7 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    if (MASK) {
+    if (MASK && c == C - 1) {  // a masked group holds exactly the chunks that are left: only the last one is cut
 #pragma unroll
       for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : f2_zero();
     }

@@ -30,6 +30,86 @@
 
 namespace ph {
 
+// Exact evaluation of a candidate period p <= kBlockWide (Periods.py:274-281), shared by the one-window and the
+// window-pair kernel so that both sum in the same order.  A short period has few residues with hundreds of rows each:
+// one thread per residue walking its column (the order of Periods.project) left all but p threads idle behind a chain
+// of N/p dependent additions -- 3 us per event, a quarter of the kernel.  Here the rows of a residue are dealt to
+// G = 2^k <= width / p threads (thread (g, j) adds rows g, g + G, ... in order), the G partial sums are combined in
+// order of g, and the trial residual's sum of squares and the update run FLAT over the samples (thread t takes
+// n = t, t + width, ... with the mean index kept incrementally).  The mean of a residue is then a differently
+// associated sum than np.sum(cp, 0) (Periods.py:194) -- within 1e-15 of it; small_to_large's bases and powers carry a
+// 1e-10 bar, only Periods.project itself (ph_project_batch) is held to bit-identity -- and np.linalg.norm has no
+// defined order anyway.  Threads >= width do nothing; msm holds >= width elements.
+// `part` (>= width elements) takes the partial sums; it may be `msm` itself (one more barrier then).
+constexpr int kS2LSplit = 16;  // most threads a residue's rows are dealt to
+struct S2LNoMark {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <typename T, typename MK = S2LNoMark>
+__device__ __forceinline__ double s2l_flat_trial(const T* __restrict__ work, T* __restrict__ msm, T* __restrict__ part, int N, int p,
+                                                 int tid, int width, MK&& mark = MK()) {
+  const Fold f(N, p);
+  int G = 1;
+  while (2 * G * p <= width && G < kS2LSplit) G <<= 1;
+  if (G == 1) {
+    if (tid < width)
+      for (int j = tid; j < p; j += width) msm[j] = residue_mean(work, f, j, false);
+  } else {
+    const int g = tid / p, j = tid - g * p;  // g < G for the threads that take part
+    if (tid < G * p) {
+      const int cnt = f.count(j);
+      const int n = cnt > g ? (cnt - g + G - 1) / G : 0;  // rows g, g + G, ... below cnt
+      part[tid] = column_sum(work + (size_t)g * p, j, G * p, n);
+    }
+    __syncthreads();
+    mark(3);
+    T s = T(0);
+    if (tid < p) {  // all G (<= 16) partials in flight, added in order of g
+      T v[kS2LSplit];
+#pragma unroll
+      for (int k = 0; k < kS2LSplit; ++k) v[k] = part[(k < G ? k : 0) * p + tid];
+      s = v[0];
+#pragma unroll
+      for (int k = 1; k < kS2LSplit; ++k) s += k < G ? v[k] : T(0);
+    }
+    if (part == msm) __syncthreads();  // every partial has been read: the first p slots now take the means
+    if (tid < p) msm[tid] = s / T(f.count(tid));
+  }
+  __syncthreads();
+  mark(4);
+  double tsq = 0.0;
+  if (tid < width) {
+    int idx = tid % p;
+    const int step = width % p;
+    for (int n = tid; n < N; n += width) {
+      const double t = (double)(work[n] - msm[idx]);
+      tsq = fma(t, t, tsq);
+      idx += step;
+      idx = idx >= p ? idx - p : idx;
+    }
+  }
+  return tsq;
+}
+
+// residual <- residual - projection for the means in `msm`; brow (optional) receives the projection, extra(n, v) sees
+// every new residual sample
+template <typename T, typename F>
+__device__ __forceinline__ void s2l_flat_update(T* __restrict__ work, const T* __restrict__ msm, int N, int p, int tid, int width,
+                                                T* __restrict__ brow, F&& extra) {
+  if (tid >= width) return;
+  int idx = tid % p;
+  const int step = width % p;
+  for (int n = tid; n < N; n += width) {
+    const T m = msm[idx];
+    const T v = work[n] - m;
+    if (brow) brow[n] = m;
+    work[n] = v;
+    extra(n, v);
+    idx += step;
+    idx = idx >= p ? idx - p : idx;
+  }
+}
+
 #ifdef PH_CLOCKS
 constexpr int kStampCap = 65536;
 __device__ long long g_ph_stamps[4 * kStampCap];  // diagnostic build only (tools/s2l_clocks.py)
@@ -39,7 +119,7 @@ enum { S2L_TICK = 0, S2L_LIMIT, S2L_STOP0, S2L_STOP1, S2L_SKIP, S2L_QWORDS = 8 }
 
 // LDS of one workgroup (host and device agree through this one function)
 __host__ __device__ inline size_t s2l_pair_lds_bytes(int N) {
-  return carve_bytes(N + kPad, 8) + carve_bytes(N, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kBlockWide, 8) + carve_bytes(8, 8) +
+  return carve_bytes(N + kPad, 8) + carve_bytes(N, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kBlockWide / 2, 8) + carve_bytes(kBlockWide, 8) + carve_bytes(8, 8) +
          carve_bytes(4, 4) + carve_bytes(4, 4) + carve_bytes(S2L_QWORDS, 4);
 }
 
@@ -75,7 +155,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   f2* pw = cv.take<f2>(N + kPad);
   double* stg = cv.take<double>(N);
   double* red = cv.take<double>(kRedDoubles);
-  double* msm = cv.take<double>(kBlockWide);  // means of a candidate period <= kBlockWide
+  double* msm = cv.take<double>(kBlockWide / 2);  // means of a candidate period dealt to several threads (<= kBlockWide / 2)
+  double* prt = cv.take<double>(kBlockWide);  // ... its partial sums; the means of a period in (kBlockWide / 2, kBlockWide]
   // per window w: st[w] ||residual||^2, st[2+w] periodic_norm(residual), st[4+w] periodic_norm(data), st[6+w] scale of
   // the float image; thf[2w], thf[2w+1]: T0, T1 of the flag test; ct[w] periods accepted
   double* st = cv.take<double>(8);
@@ -149,7 +230,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   int own = (2 * pair + 1 < W) ? 1 : -1;
   bool dirty = false, moved0 = false, moved1 = false;  // moved: the residual is no longer the input
 #ifdef PH_S2L_TIMERS
-  long long tp[4] = {0, 0, 0, 0};
+  long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tp0 = wall_clock64();
   int nev = 0, nepoch = 0, nswap = 0;
   if (tid == 0) qc[5] = 0;
@@ -166,16 +247,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const long long wk0 = wall_clock64();
 #endif
 
+  bool had_event = false;  // the epoch before this one held a barrier after its control words were read
   for (;;) {
     const int start = min(pos0, pos1);
     if (start > n_periods) break;
-    __syncthreads();  // the previous epoch's control words have been read, its thresholds written
-    if (tid == 0) {
+    if (!had_event) __syncthreads();  // the previous epoch's control words have been read
+    if (tid == bk) {
       qc[S2L_TICK] = start + nw;
       qc[S2L_LIMIT] = n_periods;
       qc[S2L_STOP0] = qc[S2L_STOP1] = qc[S2L_SKIP] = kS2LInf;
     }
-    __syncthreads();
+    __syncthreads();  // ... and: the updates of the events (residual, float image, thresholds) are complete
+    had_event = false;
     prio_long_phase();
     {
       const float t00 = thf[0], t01 = thf[1], t10 = thf[2], t11 = thf[3];
@@ -246,15 +329,22 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #ifdef PH_S2L_TIMERS
         nswap += 1;
 #endif
+        __syncthreads();
       }
-      __syncthreads();
+      had_event = true;
       const double rn = st[2 + w], dn = st[4 + w], sc = st[6 + w];
       const int count = ct[w];
       const Fold f(N, cand);
       double tsq = 0.0;
       const bool flat = cand <= kEx;  // means through LDS, sums and update flat over the samples (s2l_flat_trial)
       if (flat) {
-        tsq = s2l_flat_trial(stg, msm, N, cand, tid, kEx);
+#ifdef PH_S2L_TIMERS
+        PH_S2LQ_MARK(7)  // swap + entry
+        tsq = s2l_flat_trial(stg, cand <= kEx / 2 ? msm : prt, prt, N, cand, tid, kEx, [&](int k) { PH_S2LQ_MARK(k) });
+        PH_S2LQ_MARK(5)  // flat trial loop
+#else
+        tsq = s2l_flat_trial(stg, cand <= kEx / 2 ? msm : prt, prt, N, cand, tid, kEx);
+#endif
       } else if (ex) {
         for (int j = tid; j < cand; j += kEx) {
           const double m = residue_mean(stg, f, j, false);
@@ -265,7 +355,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           }
         }
       }
-      tsq = block_sum(tsq, red);
+      tsq = block_sum_once(tsq, red);  // `red` rests until the next event: barriers in between
       PH_S2LQ_MARK(1)
 #ifdef PH_S2L_TIMERS
       nev += 1;
@@ -275,7 +365,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       if (imposed > thresh) {  // strict, Periods.py:281
         double* brow = (bases_out && count < cap) ? bases_out + (gw * cap + count) * (int64_t)N : nullptr;
         if (flat) {
-          s2l_flat_update(stg, msm, N, cand, tid, kEx, brow, [&](int n, double v) { pwf[2 * n + w] = (float)(v * sc); });
+          s2l_flat_update(stg, cand <= kEx / 2 ? msm : prt, N, cand, tid, kEx, brow, [&](int n, double v) { pwf[2 * n + w] = (float)(v * sc); });
         } else if (ex)
           for (int j = tid; j < cand; j += kEx) {
             const double m = residue_mean(stg, f, j, false);
@@ -321,8 +411,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   }
 #ifdef PH_S2L_TIMERS
   if (pair < 6 && tid == 0)
-    printf("s2l queue timers (100 MHz ticks) screen %lld exact %lld update %lld  epochs %d events %d swaps %d passes %d accepts %d %d\n",
-           tp[0], tp[1], tp[2], nepoch, nev, nswap, qc[5], ct[0], ct[1]);
+    printf("s2l queue timers (100 MHz ticks) screen %lld exact(reduce+decide) %lld update %lld swap+entry %lld partials %lld means %lld trial %lld  epochs %d events %d swaps %d passes %d accepts %d %d\n",
+           tp[0], tp[1], tp[2], tp[7], tp[3], tp[4], tp[5], nepoch, nev, nswap, qc[5], ct[0], ct[1]);
 #endif
 #ifdef PH_CLOCKS
   if (tid == 0 && pair < kStampCap) {  // start, end (100 MHz), hardware id, accepts: read back by ph_debug_stamps

@@ -109,36 +109,55 @@ def run_sharded(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, to
     return tuple(gathered) if rank == root else None
 
 
+def piece_rows(per: int, pieces) -> list[int]:
+    """Rows of the pieces a block of `per` windows is cut into.  `pieces` is a count (equal pieces) or a sequence of
+    weights: (1, 3) = a first piece of a quarter of the block -- the only scatter no kernel hides -- and one launch for
+    the rest.  Every launch ends with a partly empty chip, so fewer and larger pieces compute faster (tools/s2l_scale.py:
+    one 8192-window launch of small_to_large 5.5 ms, two pieces 5.6, four pieces 6.2-6.7)."""
+    if isinstance(pieces, int):
+        n = max(1, min(int(pieces), max(per, 1)))
+        step = -(-per // n)
+        rows = [min(step, per - k * step) for k in range(n)]
+    else:
+        w = [float(v) for v in pieces if float(v) > 0]
+        tot = sum(w) or 1.0
+        rows, used = [], 0
+        for k, v in enumerate(w):
+            r = per - used if k == len(w) - 1 else min(per - used, int(round(per * v / tot)))
+            rows.append(r)
+            used += r
+    return [r for r in rows if r > 0] or [0]
+
+
 def run_sharded_pipelined(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, total: int, n: int, dtype,
-                          device, pieces: int = 4, root: int = 0, group=None):
-    """Like run_sharded, with the scatter cut into `pieces` asynchronous collectives per rank: all
-    of them are enqueued up front (RCCL runs them on its own stream, in order), and `fn` runs on
-    piece k as soon as it has landed while the later pieces are still in flight.  Results are
-    concatenated per rank and gathered once per output tensor."""
+                          device, pieces=(1, 3), root: int = 0, group=None):
+    """Like run_sharded, with the scatter cut into pieces (`piece_rows`) -- one asynchronous collective per piece and
+    rank: all of them are enqueued up front (RCCL runs them on its own stream, in order), and `fn` runs on piece k as
+    soon as it has landed while the later pieces are still in flight.  Results are concatenated per rank and gathered
+    once per output tensor."""
     world, rank = _world(group)
     lo, hi = shard_bounds(total, world, rank)
     if world == 1:
         return tuple(fn(x_root.to(device)))
     per = -(-total // world)
-    pieces = max(1, min(int(pieces), per))
-    step = -(-per // pieces)
+    rows_of = piece_rows(per, pieces)
     cdev = torch.device("cpu") if _host_staged(group) else device
     xr = x_root.to(cdev) if rank == root else None
-    recv, works = [], []
-    for k in range(pieces):
-        rows = min(step, per - k * step)
-        if rows <= 0:
-            break
+    recv, works, offs = [], [], []
+    off = 0
+    for rows in rows_of:
         buf = torch.empty((rows, n), dtype=dtype, device=cdev)
         lists = None
         if rank == root:
-            lists = [_rows(xr, r * per + k * step, rows, total).contiguous() for r in range(world)]
+            lists = [_rows(xr, r * per + off, rows, total).contiguous() for r in range(world)]
         works.append(dist.scatter(buf, lists, src=root, group=group, async_op=True))
         recv.append(buf)
+        offs.append(off)
+        off += rows
     outs = []
-    for k, (buf, work) in enumerate(zip(recv, works)):
+    for buf, work, off in zip(recv, works, offs):
         work.wait()  # orders the current stream behind this piece only
-        valid = max(0, min(hi - lo - k * step, buf.shape[0]))
+        valid = max(0, min(hi - lo - off, buf.shape[0]))
         outs.append(fn(buf[:valid].to(device)))
     merged = [torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))]
     gathered = [gather_rows(o, total, root, group) for o in merged]

@@ -58,7 +58,7 @@ def _worker(rank, world, port, total, n, q):
                     torch.from_numpy(np.array(pw, dtype=np.float64).reshape(-1, 3)))
 
         want = [po.m_best(row, 3) for row in multi_sinusoid_batch(0, total, n)] if rank == 0 else None
-        for runner in (run_sharded, lambda *a: run_sharded_pipelined(*a, pieces=2)):
+        for runner in (run_sharded, lambda *a: run_sharded_pipelined(*a, pieces=2), lambda *a: run_sharded_pipelined(*a, pieces=(1, 3))):
             res = runner(compute, x_root, total, n, torch.float64, torch.device("cpu"))
             if rank == 0:
                 per, pw = res
@@ -95,3 +95,16 @@ def test_empty_trailing_shard_world4():
     still take part in every collective (it used to raise before the gather and hang its peers)."""
     assert shard_bounds(5, 4, 3) == (5, 5)
     _launch(4, 5, 192)
+
+
+def test_piece_rows():
+    from pyperiod_amd.dist import piece_rows
+
+    assert piece_rows(8192, 4) == [2048] * 4
+    assert piece_rows(8192, (1, 3)) == [2048, 6144]
+    assert piece_rows(8192, 1) == [8192] and piece_rows(8192, (1,)) == [8192]
+    assert piece_rows(3, (1, 3)) == [1, 2] and piece_rows(2, (1, 3)) == [2] and piece_rows(5, 3) == [2, 2, 1]
+    assert piece_rows(0, (1, 3)) == [0] and piece_rows(1, 4) == [1]
+    for per in (1, 7, 100, 8191):
+        for pc in (1, 2, 5, (1, 3), (1, 1, 2), (0.5, 0.25, 0.25)):
+            assert sum(piece_rows(per, pc)) == per

@@ -62,6 +62,18 @@ full = timed(lambda: s2l(engs[0], xfull))
 shard = timed(lambda: s2l(engs[0], x))
 print(f"full batch 65536 windows: {full:8.3f} ms   ideal shard (1/8): {full / 8:6.3f} ms   target shard (full / 7.6): {full / 7.6:6.3f} ms")
 print(f"shard 8192 windows, one launch: {shard:6.3f} ms   -> compute-only speed-up at 8 GPUs {full / shard:5.2f}x")
+from pyperiod_amd.dist import piece_rows  # noqa: E402
+
+
+def pieces_weighted(weights):
+    off = 0
+    for rows in piece_rows(W, weights):
+        s2l(engs[0], x[off:off + rows])
+        off += rows
+
+
+a = timed(lambda: pieces_weighted((1, 3)))
+print(f"shard as run_sharded_pipelined issues it by default (pieces (1, 3): 2048 + 6144 windows): {a:6.3f} ms ({full / a:5.2f}x)")
 for n in (2, 4, 8):
     a = timed(lambda: pieces_one_stream(n))
     b = timed(lambda: pieces_two_streams(n))
