@@ -22,6 +22,11 @@ Beside it, under stable keys:
                 periods / powers; the same batch on rank 0's GPU alone is timed in the same run
                 (`speedup_vs_single_gpu`, wall and compute-only).  Consistency checks (sharded == single GPU, bit
                 for bit) make the run exit non-zero when one fails.
+  sweep_fp64    north_star's literal kernel (N = 1 only): the fused all-p projection sweep in fp64 -- ph_sweep / k_sweep, every
+                ||P_p x|| for p = 2..N/3 of 1024 windows x N=4096 written out (Periods.py:501-510), no screen, no argmax.
+  strong_scaling (N > 1) the headline figures of `c4` repeated at the top level: `value` itself is weak scaling of config 2
+                with no collective and grows ~N x by construction -- it is NOT the scaling result and not comparable with the
+                round-2 multi-GPU lines (which carried config 4 in `value`).
   c3_single_gpu BASELINE config 3 (N = 1 only): RamanujanPeriods.find_periods, 4096 windows x N=8192, q = 2..512.
   c5_single_gpu BASELINE config 5's per-GPU batch (N = 1 only): QOPeriods.find_periods, 1024 windows x N=16384 fp32.
   roofline      dominant kernel of `value`, launch time from HIP events on the kernel's own stream.  The window lives
@@ -81,12 +86,16 @@ def launch_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     live = list(procs)
-    while live and not rc:
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_DEADLINE_S", "1500"))  # a hung rendezvous must not outlive the box's limit
+    while live and not rc and time.time() < deadline:
         time.sleep(0.2)
         for p in list(live):
             if p.poll() is not None:
                 live.remove(p)
                 rc = rc or p.returncode
+    if live and not rc:
+        print(f"bench: ranks still running at the deadline, killing them", file=sys.stderr)
+        rc = 1
     for p in live:  # a rank that died leaves its peers in a collective: end them (exact PIDs, our own children)
         p.kill()
         p.wait()
@@ -288,6 +297,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit(f"--gpus {world} with backend nccl (RCCL) needs {world} GPUs, this box shows {torch.cuda.device_count()}: "
+                             "two ranks on one device cannot form a communicator (use --backend gloo for a rehearsal)")
         # the process group is created before any other GPU work of this process
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -384,6 +396,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
+            "value_note": None if world == 1 else "config 2 on every GPU, weak scaling, no data-path collective: ~N x by construction; "
+                          "the strong-scaling result (config 4 over RCCL scatter / gather) is under `strong_scaling` / `c4`",
             "vs_baseline": None,
             "dtype": "f64",
             "data": DATA,
@@ -436,6 +450,42 @@ def main():
         }
         if cpu:
             line["gpu_over_cpu"] = line["value"] / cpu["value"]
+    # =============================== the fp64 all-norms sweep (north_star's literal kernel) ===============================
+    if world == 1:
+        eng.sweep(x, 2, N_SAMPLES // 3, 0)
+        torch.cuda.synchronize(dev)
+        eng.profile(True)
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sw_out = eng.sweep(x, 2, N_SAMPLES // 3, 0)
+        torch.cuda.synchronize(dev)
+        ms_sw = 1e3 * (time.perf_counter() - t0) / reps
+        ks_ms, _ = kernel_ms(eng.profile_read(), "k_sweep")
+        eng.profile(False)
+        checks["sweep_fp64_finite"] = bool(torch.isfinite(sw_out).all().item())
+        np_sw, nper_sw = eng.sweep_plan_info(2, N_SAMPLES // 3)
+        units_sw = WINDOWS_PER_GPU * nper_sw
+        lds_sw = WINDOWS_PER_GPU * np_sw * N_SAMPLES * 8
+        trs, tss, _ = load_recorded_traffic("k_sweep")
+        sec_sw = ks_ms * 1e-3
+        line["sweep_fp64"] = {
+            "workload": f"ph_sweep norm mode: every ||P_p x|| (Periods.py:501-510), p=2..{N_SAMPLES // 3}, {WINDOWS_PER_GPU} windows x N={N_SAMPLES} fp64, "
+                        "resident in HBM, all values written out",
+            "kernel": "k_sweep<double, true>",
+            "ms": ms_sw,
+            "kernel_ms": ks_ms,
+            "window_projections_per_s": units_sw / sec_sw if sec_sw > 0 else 0.0,
+            "passes_per_sweep": np_sw,
+            "lds_frac": lds_sw / sec_sw / 1e9 / LDS_PEAK_GBS if sec_sw > 0 else 0.0,
+            "lds_frac_definition": "physical: passes x N x 8 B read from LDS per window / launch time / 150 TB/s",
+            "logical_lds_ratio": units_sw * BYTES_PER_WINDOW_PROJECTION / sec_sw / 1e9 / LDS_PEAK_GBS if sec_sw > 0 else 0.0,
+            "logical_hbm_ratio": units_sw * BYTES_PER_WINDOW_PROJECTION / sec_sw / 1e9 / HBM_PEAK_GBS if sec_sw > 0 else 0.0,
+            "compulsory_hbm_bytes": WINDOWS_PER_GPU * (N_SAMPLES + nper_sw) * 8,
+            "traffic": trs,
+            "traffic_source": tss,
+        }
+        del sw_out
     del x, out, periods, powers, bases
 
     # =============================== config 3 / config 5 on this one GPU ===============================
@@ -602,6 +652,14 @@ def main():
                                    "note": "the same batch on rank 0's GPU alone, input resident, no collective"},
                     "speedup_vs_single_gpu": single_ms / (1e3 * wall),
                     "speedup_compute_only": single_k / kms if kms else None,
+                }
+                line["strong_scaling"] = {
+                    "config": "4: small_to_large(0.05), 65 536 windows from rank 0, RCCL scatter -> compute -> RCCL gather (key c4)",
+                    "speedup_vs_single_gpu": line["c4"]["speedup_vs_single_gpu"],
+                    "speedup_compute_only": line["c4"]["speedup_compute_only"],
+                    "window_projections_per_s": line["c4"]["window_projections_per_s"],
+                    "note": "`value` is config 2, weak scaling, no collective -- it grows ~N x by construction and is not the "
+                            "scaling result; this block is.  Not comparable with round-2 lines, whose `value` was config 4.",
                 }
             barrier()
 
