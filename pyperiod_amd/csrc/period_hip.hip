@@ -480,7 +480,7 @@ size_t pair_lds_bytes(int N, int num, int P) {
   return 2 * carve_bytes(N + kPad, 8) + carve_bytes(kRedDoubles, 8) + carve_bytes(kMaxWaves, 8) +
          carve_bytes(kMaxWaves, 4) + carve_bytes(2 * num, 8) + carve_bytes(2 * num, 4) +
          carve_bytes(2 * ((P + 31) / 32), 4) + carve_bytes(2 * ph::kPairListCap, 4) + carve_bytes(16, 4) +
-         carve_bytes(4, 8) + carve_bytes(ph::kPairSmallP, 8);
+         carve_bytes(4, 8) + carve_bytes(ph::kPairSmallP, 8) + carve_bytes(ph::kPairSplitW, 8);
 }
 
 // The window-pair screen serves fp64 windows, plain projection, candidate periods below N, when the pair window
@@ -826,6 +826,10 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
   size_t lds2 = carve_bytes(N + kPad, sz) + carve_bytes(N, sz) + carve_bytes(kRedDoubles, 8) +
                 carve_bytes(num, 8) + carve_bytes(num, 4) + carve_bytes(max_fac, 8) + carve_bytes(max_fac, 4) +
                 carve_bytes(kMaxWaves, sizeof(ph::PGeom)) + 3 * carve_bytes(num, 4) + carve_bytes(std::max(max_fac, 64), 4);
+  // LDS for the means of a short winning period (split_row_means): only when the window stays in LDS beside it
+  const size_t lds_small = carve_bytes(ph::kPairSmallP, sz) + carve_bytes(ph::kPairSplitW, sz);
+  const int small_means = (!general && lds1 + lds_small <= (size_t)c->lds_limit) ? 1 : 0;
+  if (small_means) lds1 += lds_small;
   void *gbuf1, *gbuf2;
   PH_TRY(place_second_buffer(c, &lds1, general, (size_t)N * sz, W, &gbuf1));
   // step 2 materialises a projection only when a row is split (rare) or in the trunc/orth modes:
@@ -899,7 +903,7 @@ int ph_m_best(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int num, in
                                                                          : c->sweep_block;
     hipLaunchKernelGGL(kernel, grid, dim3(block1), lds1, c->stream, (const T*)dx, N, num, min_length,
                        max_length, gamma, kflags, tb, geom, plan, n_pass, (T*)gbuf1, (T*)gwin1, max_iters,
-                       (uint32_t*)dper, (double*)dpow, (T*)drows, row_stride, dnorm, (int*)dstat, (int*)dsweeps);
+                       (uint32_t*)dper, (double*)dpow, (T*)drows, row_stride, dnorm, (int*)dstat, (int*)dsweeps, small_means);
     return (int)PH_OK;
   }));
   PH_TRY(launch_check("k_mbest_step1"));

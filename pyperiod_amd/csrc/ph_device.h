@@ -212,6 +212,51 @@ __device__ __forceinline__ T residue_mean(const T* __restrict__ xs, const Fold& 
   return s / T(div);
 }
 
+// Means of a SHORT period with its rows dealt to several threads.  One thread per residue walking its column (the
+// order of np.sum(cp, 0), Periods.py:194) leaves all but p threads idle behind a chain of N / p dependent additions:
+// 3 us for an accepted period of small_to_large, 12 us for the period-3 winner of an m_best_gamma sweep.  Here
+// thread (g, j), g < G = 2^k <= min(kSplitMax, width / p), adds rows g, g + G, ... of residue j in order, the G
+// partial sums are combined in order of g (16 LDS reads in flight at a time), and msm[j] = S_j / cnt_j.  The sum is
+// associated differently from the reference's -- within a few ulp of it; results that carry the 1e-10 bar (bases,
+// powers of the sweeps) may use it, Periods.project itself (ph_project_batch) keeps the row order.
+// `part` holds >= G p <= width elements and may be `msm` itself (one more barrier then); ends with a barrier: on
+// return msm[0 .. p) is complete for every thread.  Threads >= width take no part.
+constexpr int kSplitMax = 64;
+template <typename T>
+__device__ __forceinline__ void split_row_means(const T* __restrict__ work, T* msm, T* part, int N, int p, int tid, int width) {
+  const int rows = (N + p - 1) / p, nfull = p - (rows * p - N);  // Fold(N, p)
+  int G = 1;
+  while (2 * G * p <= width && G < kSplitMax) G <<= 1;
+  if (G == 1) {
+    if (tid < width)
+      for (int j = tid; j < p; j += width) {
+        const int cnt = j < nfull ? rows : rows - 1;
+        msm[j] = column_sum(work, j, p, cnt) / T(cnt);
+      }
+  } else {
+    const int g = tid / p, j = tid - g * p;  // g < G for the threads that take part
+    if (tid < G * p) {
+      const int cnt = j < nfull ? rows : rows - 1;
+      const int n = cnt > g ? (cnt - g + G - 1) / G : 0;  // rows g, g + G, ... below cnt
+      part[tid] = column_sum(work + (size_t)g * p, j, G * p, n);
+    }
+    __syncthreads();
+    T s = T(0);
+    if (tid < p) {
+      for (int k0 = 0; k0 < G; k0 += 16) {  // G is 2, 4, 8 or a multiple of 16
+        T v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = part[(k0 + k < G ? k0 + k : 0) * p + tid];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += k0 + k < G ? v[k] : T(0);
+      }
+    }
+    if (part == msm) __syncthreads();  // every partial has been read: the first p slots now take the means
+    if (tid < p) msm[tid] = s / T(tid < nfull ? rows : rows - 1);
+  }
+  __syncthreads();
+}
+
 // dst[n] = mean[n mod p] for all n < N (tile, Periods.py:196-198); src and dst are LDS.
 // Each thread only touches its own residue columns, so src == dst would also be legal.
 template <typename T>

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   }
 }
 
+constexpr int kPairSmallP = 256;  // winners up to this period: means through LDS, subtraction by all threads
+constexpr int kPairSplitW = 512;  // threads that share the rows of a short winner's residues (split_row_means)
+
 // ======================================================================================
 // m_best step 1  (Periods.py:494-537): repeat { all-p sweep, argmax, subtract } until `num`
 // distinct periods are found.  One workgroup per window, one launch per window batch.
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
                                                         double* __restrict__ norms_out, T* __restrict__ rows_out,
                                                         int row_stride, double* __restrict__ dnorm_out,
                                                         int* __restrict__ status_out,
-                                                        int* __restrict__ sweeps_out) {
+                                                        int* __restrict__ sweeps_out, int small_means) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Carve cv(smem);
   T* work = window_buf<T, LW>(cv, gwin, N + kPad);
@@ -202,6 +205,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   uint32_t* periods = cv.take<uint32_t>(num);
   const int P = p_hi - p_lo + 1;
   uint32_t* skip = cv.take<uint32_t>((P + 31) / 32);
+  // means / partial sums of a short winning period (split_row_means); absent when the LDS has no room for them
+  T* msm = small_means ? cv.take<T>(kPairSmallP) : nullptr;
+  T* prt = small_means ? cv.take<T>(kPairSplitW) : nullptr;
 
   const int64_t w = blockIdx.x;
   const int tid = threadIdx.x;
@@ -321,7 +327,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     }
     // ---- project the winner, update bases row, subtract from the residual (:531-537)
     T* brow = rows + (int64_t)(row < 0 ? 0 : row) * row_stride;
-    if (!general) {
+    if (!general && msm && bestp <= kPairSmallP) {
+      // a short period: its few residues have hundreds of rows each -- means through LDS (split_row_means, as
+      // k_mbest_step1_pair), the subtraction is spread over the workgroup
+      split_row_means(work, msm, prt, N, bestp, tid, min((int)blockDim.x, kPairSplitW));
+      if (tid < bestp) {
+        const T m = msm[tid];
+        if (action == 1)
+          brow[tid] = m;
+        else if (action == 2)
+          brow[tid] += m;
+      }
+      int idx = tid % bestp;
+      const int step = blockDim.x % bestp;
+      for (int n = tid; n < N; n += blockDim.x) {
+        work[n] -= msm[idx];
+        idx += step;
+        idx = idx >= bestp ? idx - bestp : idx;
+      }
+    } else if (!general) {
       const Fold f(N, bestp);
       for (int j = tid; j < bestp; j += blockDim.x) {
         const T m = residue_mean(work, f, j, false);
@@ -382,7 +406,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
 #endif
 constexpr int kPairListCap = 96;
 constexpr int kPairCoop = 6;  // up to this many survivors are evaluated by the whole workgroup, one after the other
-constexpr int kPairSmallP = 256;  // winners up to this period: means through LDS, subtraction by all threads
 
 __device__ __forceinline__ bool pair_usable(double rsq) { return rsq > 0.0 && rsq < 1.79e308; }
 
@@ -434,6 +457,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   int* ctl = cv.take<int>(16);
   double* dst2 = cv.take<double>(4);  // [w] sum of squares of the scaled residual (unit of the radius), [2+w] its scale
   double* msm = cv.take<double>(kPairSmallP);  // means of a short winning period
+  double* prt = cv.take<double>(kPairSplitW);  // partial sums of split_row_means
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -697,17 +721,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
           double acc = 0.0;
           const Fold f(N, bestp);
           if (bestp <= kPairSmallP) {
-            // a short period (the usual winner of m_best_gamma): its few residues have hundreds of rows each -- the
-            // row-order means stay with one thread per residue, the subtraction is spread over the workgroup
-            for (int j = tid; j < bestp; j += blockDim.x) {
-              const double m = residue_mean(stg, f, j, false);
-              msm[j] = m;
+            // a short period: its few residues have hundreds of rows each -- means through LDS, the subtraction is spread
+            // over the workgroup
+            // (the usual winner of m_best_gamma); split_row_means deals the rows of a residue to several threads
+            split_row_means(stg, msm, prt, N, bestp, tid, kPairSplitW);
+            if (tid < bestp) {
+              const double m = msm[tid];
               if (action == 1)
-                brow[j] = m;
+                brow[tid] = m;
               else if (action == 2)
-                brow[j] += m;
+                brow[tid] += m;
             }
-            __syncthreads();
             if (more) {
               int idx = tid % bestp;
               const int step = blockDim.x % bestp;
@@ -2035,6 +2059,9 @@ constexpr int kRamMaxWaves = 16;
 #ifndef PH_RAM_U
 #define PH_RAM_U 4
 #endif
+#ifndef PH_RAM_FOLD_V1
+#define PH_RAM_FOLD_V1 0  // 1: the round-3 root fold (blocks of PH_RAM_U rows, leftover rows one at a time)
+#endif
 
 // Everything the kernel needs to know about one period, in ONE 128-byte record (two s_load_dwordx16): the strip
 // steps of a wavefront are chains of dependent LDS round trips with 3-4 wavefronts per SIMD to hide them, and the
@@ -2071,6 +2098,99 @@ __device__ __forceinline__ void fold_store_group(const T* __restrict__ xs, int p
     const bool has = j < nfull;
     const T v = xs[has ? (rows - 1) * p + j : 0];
     if (j < p) sbuf[j] = s[c] + (has ? (double)v : 0.0);
+  }
+}
+
+// Root fold without remainder rows (round 4).  fold_store_group above takes the rows of a residue in blocks of U and
+// then drains after every single leftover row and after the partial last row: at config 3 (22 rows of 6 chunks per
+// root) a group issued 5 full batches and up to 4 one-row batches, each a full LDS round trip with 4 wavefronts per
+// SIMD to hide it -- the folds ran at 0.55 of the streaming LDS rate although the bare 16-loads / drain / 16-adds
+// pattern reaches 0.85 at that occupancy (tools/micro/lds_pipe_bench 1024 163840).  Here the `rows` rows of a root are
+// cut into k = ceil(rows / 8) batches of U or U + 1 rows (U = rows / k, compile time), every batch fully in flight
+// before its one wait, and the partial last row is the last row of the last batch (lanes without it read element 0
+// and add nothing).  The order of the additions per residue is unchanged (row 0, 1, ..., rows - 1).
+template <typename T, int C, int NR, bool LAST, bool LW>
+__device__ __forceinline__ void ram_fold_batch(typename Win<T, LW>::ptr ptr, typename Win<T, LW>::ptr x0, int p, const bool (&has)[C],
+                                               double (&s)[C]) {
+  T v[NR][C];
+#pragma unroll
+  for (int u = 0; u < NR; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (LAST && u == NR - 1)
+        v[u][c] = has[c] ? ptr[u * p + 64 * c] : x0[0];
+      else
+        v[u][c] = ptr[u * p + 64 * c];
+    }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < NR; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] += (LAST && u == NR - 1) ? (has[c] ? (double)v[u][c] : 0.0) : (double)v[u][c];
+}
+
+template <typename T, int C, int U, bool LW>
+__device__ __forceinline__ void ram_fold_group(const T* __restrict__ xs, int p, int nfull, int k, int rem, int c0, int lane,
+                                               double* __restrict__ sbuf) {
+  typedef typename Win<T, LW>::ptr wptr;
+  double s[C];
+  bool has[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    s[c] = 0.0;
+    has[c] = 64 * (c0 + c) + lane < nfull;
+  }
+  const wptr x0 = Win<T, LW>::cast(xs);
+  wptr ptr = x0 + lane + 64 * c0;
+  int b = 0;
+  for (; b < rem; ++b) {  // rem < k batches of U + 1 rows
+    ram_fold_batch<T, C, U + 1, false, LW>(ptr, x0, p, has, s);
+    ptr += (U + 1) * p;
+  }
+  for (; b + 1 < k; ++b) {
+    ram_fold_batch<T, C, U, false, LW>(ptr, x0, p, has, s);
+    ptr += U * p;
+  }
+  ram_fold_batch<T, C, U, true, LW>(ptr, x0, p, has, s);  // ends with the partial row
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = 64 * (c0 + c) + lane;
+    if (j < p) sbuf[j] = s[c];
+  }
+}
+
+template <typename T, int U, bool LW>
+__device__ __forceinline__ void ram_root_fold_u(const T* __restrict__ xs, int Q, int nfull, int k, int rem, int lane,
+                                                double* __restrict__ sbuf) {
+  const int nchunks = (Q + 63) >> 6;
+  int k0 = 0;
+  for (; k0 + 4 <= nchunks; k0 += 4) ram_fold_group<T, 4, U, LW>(xs, Q, nfull, k, rem, k0, lane, sbuf);
+  switch (nchunks - k0) {
+    case 3: ram_fold_group<T, 3, U, LW>(xs, Q, nfull, k, rem, k0, lane, sbuf); break;
+    case 2: ram_fold_group<T, 2, U, LW>(xs, Q, nfull, k, rem, k0, lane, sbuf); break;
+    case 1: ram_fold_group<T, 1, U, LW>(xs, Q, nfull, k, rem, k0, lane, sbuf); break;
+    default: break;
+  }
+}
+
+// S_Q of the window into the strip, Q >= 64 (rows = ceil(N / Q) >= 1)
+template <typename T, bool LW>
+__device__ __forceinline__ void ram_root_fold(const T* __restrict__ xs, int Q, int rows, int nfull, int lane,
+                                              double* __restrict__ sbuf) {
+  const int k = (rows + 7) >> 3;  // batches
+  int U = 1;                      // rows / k without a division (k <= rows, the quotient is in 1 .. 8)
+  while ((U + 1) * k <= rows) ++U;
+  const int rem = rows - U * k;
+  switch (U) {
+    case 1: ram_root_fold_u<T, 1, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    case 2: ram_root_fold_u<T, 2, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    case 3: ram_root_fold_u<T, 3, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    case 4: ram_root_fold_u<T, 4, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    case 5: ram_root_fold_u<T, 5, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    case 6: ram_root_fold_u<T, 6, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    case 7: ram_root_fold_u<T, 7, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
+    default: ram_root_fold_u<T, 8, LW>(xs, Q, nfull, k, rem, lane, sbuf); break;
   }
 }
 
@@ -2345,11 +2465,10 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
       const double tot = wave_fold_small(xs, N, Q, lane);  // row-split path, S_Q[lane] in the lanes below Q
       if (lane < Q) sA[lane] = tot;
     } else {
+#if PH_RAM_FOLD_V1
       const int rows = R.rows, nfull = R.nfull;
       const int nchunks = (Q + 63) >> 6;
       int k0 = 0;
-      // LDS capacity (window + strips) caps this kernel at 3-4 wavefronts per SIMD, so registers are
-      // plentiful: PH_RAM_U rows x 4 chunks of loads in flight per wait
       for (; k0 + 4 <= nchunks; k0 += 4) fold_store_group<T, 4, PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA);
       switch (nchunks - k0) {
         case 3: fold_store_group<T, 3, PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
@@ -2357,8 +2476,19 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
         case 1: fold_store_group<T, 1, 4 * PH_RAM_U, LW>(xs, Q, rows, nfull, k0, lane, sA); break;
         default: break;
       }
+#else
+      // LDS capacity (window + strips) caps this kernel at 3-4 wavefronts per SIMD, so registers are plentiful:
+      // batches of up to 9 rows x 4 chunks of loads in flight per wait, no leftover rows (ram_root_fold)
+      ram_root_fold<T, LW>(xs, Q, R.rows, R.nfull, lane, sA);
+#endif
     }
     ram_wave_sync();
+#ifdef PH_RAM_FOLDS_ONLY  // profiling aid (results incomplete): the root folds alone, one strip element kept alive
+    if (lane == 0) orow[Q] = sA[Q >> 1];
+    ram_wave_sync();
+    i = nw + __builtin_amdgcn_readfirstlane(nxt);
+    continue;
+#endif
     // ---- children: fold of the strip, filtered in the scratch strip
     for (int c = R.c0; c < R.c1; ++c) {
       const RamJob C = children[c];
@@ -2380,7 +2510,7 @@ __global__ __launch_bounds__(kRamMaxWaves * 64) void k_ramanujan(const T* __rest
 #ifdef PH_CLOCKS
   if ((blockIdx.x == 7 || blockIdx.x == 2000) && threadIdx.x == 0) {
     const long long ck2 = clock64(), wk2 = wall_clock64();
-    printf("k_ramanujan wg %d: load %lld cycles / %lld ticks(100MHz), work %lld cycles / %lld ticks -> %.0f MHz\n", (int)blockIdx.x,
+    printf("k_ramanujan window %d: load %lld cycles / %lld ticks(100MHz), work %lld cycles / %lld ticks -> %.0f MHz\n", (int)w,
            ck1 - ck0, wk1 - wk0, ck2 - ck1, wk2 - wk1, 100.0 * (double)(ck2 - ck1) / (double)(wk2 - wk1));
   }
 #endif

@@ -33,49 +33,21 @@ namespace ph {
 // Exact evaluation of a candidate period p <= kBlockWide (Periods.py:274-281), shared by the one-window and the
 // window-pair kernel so that both sum in the same order.  A short period has few residues with hundreds of rows each:
 // one thread per residue walking its column (the order of Periods.project) left all but p threads idle behind a chain
-// of N/p dependent additions -- 3 us per event, a quarter of the kernel.  Here the rows of a residue are dealt to
-// G = 2^k <= width / p threads (thread (g, j) adds rows g, g + G, ... in order), the G partial sums are combined in
-// order of g, and the trial residual's sum of squares and the update run FLAT over the samples (thread t takes
+// of N/p dependent additions -- 3 us per event, a quarter of the kernel.  Here the means come from split_row_means
+// (ph_device.h: the rows of a residue dealt to up to 64 threads, partial sums combined in a fixed order), and the
+// trial residual's sum of squares and the update run FLAT over the samples (thread t takes
 // n = t, t + width, ... with the mean index kept incrementally).  The mean of a residue is then a differently
 // associated sum than np.sum(cp, 0) (Periods.py:194) -- within 1e-15 of it; small_to_large's bases and powers carry a
 // 1e-10 bar, only Periods.project itself (ph_project_batch) is held to bit-identity -- and np.linalg.norm has no
 // defined order anyway.  Threads >= width do nothing; msm holds >= width elements.
-// `part` (>= width elements) takes the partial sums; it may be `msm` itself (one more barrier then).
-constexpr int kS2LSplit = 16;  // most threads a residue's rows are dealt to
+// `part` (>= width elements) takes the partial sums of split_row_means; it may be `msm` itself (one more barrier then).
 struct S2LNoMark {
   __device__ __forceinline__ void operator()(int) const {}
 };
 template <typename T, typename MK = S2LNoMark>
-__device__ __forceinline__ double s2l_flat_trial(const T* __restrict__ work, T* __restrict__ msm, T* __restrict__ part, int N, int p,
-                                                 int tid, int width, MK&& mark = MK()) {
-  const Fold f(N, p);
-  int G = 1;
-  while (2 * G * p <= width && G < kS2LSplit) G <<= 1;
-  if (G == 1) {
-    if (tid < width)
-      for (int j = tid; j < p; j += width) msm[j] = residue_mean(work, f, j, false);
-  } else {
-    const int g = tid / p, j = tid - g * p;  // g < G for the threads that take part
-    if (tid < G * p) {
-      const int cnt = f.count(j);
-      const int n = cnt > g ? (cnt - g + G - 1) / G : 0;  // rows g, g + G, ... below cnt
-      part[tid] = column_sum(work + (size_t)g * p, j, G * p, n);
-    }
-    __syncthreads();
-    mark(3);
-    T s = T(0);
-    if (tid < p) {  // all G (<= 16) partials in flight, added in order of g
-      T v[kS2LSplit];
-#pragma unroll
-      for (int k = 0; k < kS2LSplit; ++k) v[k] = part[(k < G ? k : 0) * p + tid];
-      s = v[0];
-#pragma unroll
-      for (int k = 1; k < kS2LSplit; ++k) s += k < G ? v[k] : T(0);
-    }
-    if (part == msm) __syncthreads();  // every partial has been read: the first p slots now take the means
-    if (tid < p) msm[tid] = s / T(f.count(tid));
-  }
-  __syncthreads();
+__device__ __forceinline__ double s2l_flat_trial(const T* __restrict__ work, T* msm, T* part, int N, int p, int tid, int width,
+                                                 MK&& mark = MK()) {
+  split_row_means(work, msm, part, N, p, tid, width);
   mark(4);
   double tsq = 0.0;
   if (tid < width) {

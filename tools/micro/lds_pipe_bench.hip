@@ -6,10 +6,11 @@
 //   hipcc --offload-arch=gfx950 -O3 lds_pipe_bench.hip -o lds_pipe_bench && ./lds_pipe_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef double v1d;
 #define RD(dst, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 template <int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k(int iters, int rowbytes, double* out) {
+__global__ __launch_bounds__(1024) void k(int iters, int rowbytes, double* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) ((double*)smem)[i] = 1e-9 * i;
   __syncthreads();
@@ -43,8 +44,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (MODE == 2) { acc0 += a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; }
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc0 + acc1 + acc2 + acc3;
 }
-int main() {
-  const int blocks = 1024, threads = 512, iters = 20000;
+int main(int argc, char** argv) {
+  // argv: threads per workgroup, LDS bytes per workgroup (occupancy), iterations: `1024 163840` = one 16-wave workgroup per CU (4 waves per SIMD)
+  const int threads = argc > 1 ? atoi(argv[1]) : 512, lds = argc > 2 ? atoi(argv[2]) : 16384, iters = argc > 3 ? atoi(argv[3]) : 5000;
+  const int blocks = 1024;
+  setvbuf(stdout, NULL, _IONBF, 0);
   double* o; hipMalloc(&o, (size_t)blocks * threads * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const char* names[3] = {"S stream, no wait      ", "A 16 loads/drain/16 adds", "B 8+8 never drained     "};
@@ -53,12 +57,13 @@ int main() {
     float best = 1e9;
     for (int r = 0; r < 3; ++r) {
       hipEventRecord(e0);
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), 16384, 0, iters, 4096, o);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, 0, iters, 4096, o);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
     }
     const double bytes = (double)blocks * (threads / 64) * iters * 16 * 512;
-    printf("%s: %.3f ms  %.1f TB/s\n", names[mode], best, bytes / (best * 1e-3) / 1e12);
+    printf("threads %d lds %d | %s: %.3f ms  %.1f TB/s\n", threads, lds, names[mode], best, bytes / (best * 1e-3) / 1e12);
   }
   return 0;
 }
