@@ -2580,6 +2580,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_sum(const double* __restrict__ 
 // solve, a period that adds no new rows, or a repeated period -- the cases that make the reference's
 // matrix singular).  counts[w] = {periods reported, blocks in the dictionary}.
 // ======================================================================================
+#ifndef PH_QO_OCC
+#define PH_QO_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))  // two 16-wave workgroups per CU need <= 64 VGPRs
+#endif
 constexpr int kQoMaxBlocks = 64;
 constexpr int kQoPairTab = 16;  // dictionaries of up to this many blocks keep their pair constants in LDS
 
@@ -2643,7 +2646,7 @@ __device__ __forceinline__ double qo_offdiag(const double* __restrict__ vb, int 
 }
 
 template <typename T, bool LW>
-__global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
+__global__ __launch_bounds__(1024) PH_QO_OCC void k_qo_find(const T* __restrict__ x, int N, int num, double thresh,
                                                         int p_lo, int p_hi, const PGeom* __restrict__ geom,
                                                         const PassPlan* __restrict__ plan, int n_pass,
                                                         const int* __restrict__ phi, const int* __restrict__ div_off,
@@ -2945,7 +2948,9 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
         bb = fma(bval, bval, bb);
       }
       bb = block_sum(bb, red);  // (its barriers also publish zv)
-      const double tol = sizeof(T) == 4 ? 1e-11 : 1e-13;  // ||r|| <= tol ||A x||
+      // ||r|| <= tol ||A x||: with the condition numbers seen (kappa ~ 3000) the weights are then good to 3e-10 (fp64
+      // windows, bar 1e-8) and 3e-6 (float windows, whose residual is stored as float; bar 1e-4)
+      const double tol = sizeof(T) == 4 ? 1e-9 : 1e-13;
       const double tol2 = tol * tol * bb;
       const int itmax = 4 * K + 100;
       double gamma_old = 0.0, alpha = 0.0, rr = 1.0 / 0.0;
@@ -2963,16 +2968,10 @@ __global__ __launch_bounds__(1024) void k_qo_find(const T* __restrict__ x, int N
           part[2 * kMaxWaves + wv] = sr;
         }
         __syncthreads();
-        double g = 0.0, d = 0.0;
-        rr = 0.0;
-        for (int i = 0; i < nw; ++i) {
-          g += part[i];
-          d += part[kMaxWaves + i];
-          rr += part[2 * kMaxWaves + i];
-        }
-        g = uniform_f64(g);
-        d = uniform_f64(d);
-        rr = uniform_f64(rr);
+        // (all reads in flight before the first addition: the loop over the run-time wave count was 3 x 16 dependent
+        // LDS round trips per iteration)
+        const double g = uniform_f64(red_combine(part, nw)), d = uniform_f64(red_combine(part + kMaxWaves, nw));
+        rr = uniform_f64(red_combine(part + 2 * kMaxWaves, nw));
         if (rr <= tol2 || iter >= itmax) break;
         const double beta = iter == 0 ? 0.0 : g / gamma_old;
         const double denom = iter == 0 ? d : d - beta * g / alpha;
