@@ -441,6 +441,8 @@ def main():
                 # elements of each row); step 2 writes the (num, N) matrix once (its launch: step2_launch_ms)
                 "compulsory_hbm_bytes_per_launch": WINDOWS_PER_GPU * N_SAMPLES * 8 + WINDOWS_PER_GPU * NUM_PERIODS * (N_SAMPLES // 3) * 8,
                 "compulsory_hbm_bytes_step2": WINDOWS_PER_GPU * NUM_PERIODS * (N_SAMPLES // 3 + N_SAMPLES) * 8,
+                # > 1: the pair kernel's fp64 residuals make one round trip through the HBM workspace per sweep and window
+                "traffic_over_compulsory": (traffic / (WINDOWS_PER_GPU * N_SAMPLES * 8 + WINDOWS_PER_GPU * NUM_PERIODS * (N_SAMPLES // 3) * 8)) if traffic else None,
                 "note": "SURVEY 8d's logical figure (N*8 B per window-projection against 8 TB/s) is logical_hbm_ratio; it "
                 "exceeds 1 because the fused sweep serves every pass but the first from LDS.  The kernel is bound by "
                 "instruction issue (VALU + LDS pipe): frac is the physical LDS utilisation, logical_lds_ratio what an "
@@ -580,6 +582,10 @@ def main():
                 "logical_lds_ratio": units * BYTES_PER_WINDOW_PROJECTION / (k4_ms * 1e-3) / 1e9 / LDS_PEAK_GBS if k4_ms else None,
                 "traffic_8192_window_shard": tr4,
                 "traffic_source": ts4,
+                # windows in + counts / periods / powers out; the rest of the recorded traffic is the staging buffer's
+                # write-back cache moving fp64 residuals between LDS and the HBM workspace
+                "compulsory_hbm_bytes_8192_window_shard": 8192 * (N_SAMPLES * 8 + 4 + C4_CAP * 12 + 4),
+                "traffic_over_compulsory": (tr4 / (8192 * (N_SAMPLES * 8 + 4 + C4_CAP * 12 + 4))) if tr4 else None,
             }
         else:
             # strong scaling: batch on rank 0 -> scatter -> compute -> gather

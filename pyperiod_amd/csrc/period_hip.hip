@@ -621,7 +621,7 @@ int ph_set_stream(ph_ctx* c, void* hip_stream) {
 int ph_sweep_plan_info(ph_ctx* c, int p_lo, int p_hi, int* n_pass, int* n_periods) {
   if (!c || !n_pass || !n_periods) return fail(PH_E_ARG, "NULL argument");
   if (p_lo < 1 || p_hi < p_lo) return fail(PH_E_ARG, "need 1 <= p_lo <= p_hi (got %d, %d)", p_lo, p_hi);
-  *n_pass = (int)build_plan(p_lo, p_hi, c->plan_max_m).size();
+  *n_pass = (int)build_plan(p_lo, p_hi, c->plan_max_m, true, c->pair_chain).size();  // the plan ph_sweep's norm modes run
   *n_periods = p_hi - p_lo + 1;
   return PH_OK;
 }
@@ -763,7 +763,7 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   PH_HIP(hipSetDevice(c->device));
   const size_t sz = elem_size(dtype);
   const bool general = (flags & (PH_FLAG_TRUNC | PH_FLAG_ORTH)) && mode != PH_SWEEP_MAXABS;
-  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8);
+  size_t lds = carve_bytes(N + kPad, sz) + (general ? carve_bytes(N, sz) : 0) + carve_bytes(kRedDoubles, 8) + carve_bytes(4, 4);
   const int P = p_hi - p_lo + 1;
   // long windows (at most two workgroups per CU): 16 wavefronts per workgroup
   const int sweep_block = (3 * lds > (size_t)c->lds_limit && c->sweep_block == ph::kBlockWide) ? 1024 : c->sweep_block;
@@ -777,7 +777,8 @@ int ph_sweep(ph_ctx* c, const void* x, int dtype, int64_t W, int N, int p_lo, in
   PH_TRY(prepare_geom(c, N, p_hi, &geom));
   const ph::PassPlan* plan;
   int n_pass;
-  PH_TRY(prepare_plan(c, p_lo, p_hi, &plan, &n_pass));
+  // norm modes: the periods up to 64 in chains (one row-split pass yields L, L/2, ...: wave_chain_small)
+  PH_TRY(prepare_plan(c, p_lo, p_hi, &plan, &n_pass, 4, true, true));
   ph::Tables tb{};
   PH_TRY(prepare_orth(c, general ? flags : 0u, orth_off, orth_q, table_max_p, p_hi, &tb));
   Stage st(c, flags);

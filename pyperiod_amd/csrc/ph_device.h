@@ -851,15 +851,47 @@ struct Butterfly8 {
 // Norm sweep driven by a pass plan: visits ||P_q x||^2 of every period the passes
 // plan[i_first], plan[i_first + stride], ... (< i_end) produce.  Periods arrive out of order;
 // consume(value, q) runs in the 8 lanes that own q.
+// Chains of periods up to 64 (PassPlan.m = 8 + levels, round 4 for the fp64 sweeps; ph_pair.h has the float-pair
+// form): the row-split fold at L leaves S_L[l] in the lanes l < L, and S_{L/2}[l] = S_L[l] + S_L[l + L/2] -- one
+// pass of N / L loads yields L, L/2, ..., L / 2^(levels-1).  A period below 64 cost twice an average pass.
+template <typename T, bool MAXABS, typename BF, typename F>
+__device__ __forceinline__ void wave_chain_small(const T* __restrict__ xs, int N, int L, int nlev, const PGeom* __restrict__ geom,
+                                                 int lane, BF& bf, F&& consume) {
+  double tot = wave_fold_small(xs, N, L, lane);
+  int q = L;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const PGeom g = geom[q];
+    const double w = (lane < g.nfull) ? g.w_full : g.w_short;
+    const double a = lane < q ? (MAXABS ? fabs(tot) : tot * tot * w) : 0.0;
+    bf.push(a, q, lane, consume);
+    if (lev + 1 < nlev) {
+      q >>= 1;
+      tot += __shfl(tot, (lane + q) & (kWave - 1), kWave);  // lanes < q read lanes < 2 q: totals of the level above
+    }
+  }
+}
+
+// `queue` (an LDS counter the caller has set to i_first's base + stride, i.e. the first index no wavefront starts
+// with): the passes are taken in plan order by whichever wavefront is free instead of strided.
 template <typename T, bool LDS, bool MAXABS = false, typename F>
 __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N, const PGeom* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end,
-                                                int stride, int lane, F&& consume) {
+                                                int stride, int lane, F&& consume, int* __restrict__ queue = nullptr) {
   Butterfly8<MAXABS> bf;
   bf.reset();
-  for (int i = i_first; i < i_end; i += stride) {
-    const int p = plan[i].p, m = plan[i].m;
-    if (m <= 1) {
+  for (int i = i_first; i < i_end;) {
+    int nxt = i + stride;
+    if (queue) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(queue, 1);
+      nxt = __builtin_amdgcn_readfirstlane(t);
+    }
+    const int i_now = i;
+    i = nxt;
+    const int p = plan[i_now].p, m = plan[i_now].m;
+    if (m >= 8) {
+      wave_chain_small<T, MAXABS>(xs, N, p, m - 8, geom, lane, bf, consume);
+    } else if (m <= 1) {
       bf.push(wave_partial<T, MAXABS, LDS>(xs, N, p, geom[p], lane), p, lane, consume);
     } else if (m == 2) {
       double part[3];

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   const bool general = (flags & (kTrunc | kOrth)) && mode != 2;
   T* buf = !general ? nullptr : gbuf ? gbuf + (int64_t)blockIdx.x * N : cv.take<T>(N);
   double* red = cv.take<double>(kRedDoubles);
+  int* qctr = cv.take<int>(4);  // pass queue of the norm modes
 
   const int64_t w = blockIdx.x / chunks;
   const int c = blockIdx.x % chunks;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   const int pb = min(p_hi, pa + per - 1);
   load_window(x + w * (int64_t)N, xs, N);
   zero_pad(xs, N);
+  if (threadIdx.x == 0) qctr[0] = c * ((n_pass + chunks - 1) / chunks) + (int)(blockDim.x >> 6);
   __syncthreads();
   double* orow = out + w * (int64_t)P;
 
@@ -163,9 +165,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       // norm modes: the workgroups of a window split the pass plan, not the period range
       const int pper = (n_pass + chunks - 1) / chunks;
       const int i0 = c * pper, i1 = min(n_pass, i0 + pper);
-      wave_sweep_plan<T, LW>(xs, N, geom, plan, i0 + wv, i1, nw, lane, [&](double v, int p) {
-        if ((lane & 7) == 0) orow[p - p_lo] = periodic_norm_from_sq(v, N, mode == 1 ? p : 0);
-      });
+      wave_sweep_plan<T, LW>(
+          xs, N, geom, plan, i0 + wv, i1, nw, lane,
+          [&](double v, int p) {
+            if ((lane & 7) == 0) orow[p - p_lo] = periodic_norm_from_sq(v, N, mode == 1 ? p : 0);
+          },
+          qctr);
     }
   } else {
     for (int p = pa; p <= pb; ++p) {

@@ -291,7 +291,7 @@ def test_small_to_large_device_pointer_cap_overflow_is_reported(eng):
 def test_plan_info_and_feasibility_helpers(eng):
     n_pass, n_per = eng.sweep_plan_info(2, 1365)
     assert n_per == 1364 and 600 < n_pass < 1364  # multi-period passes: fewer passes than periods
-    assert eng.sweep_plan_info(2, 63) == (62, 62)  # below 64 every period is its own (row-split) pass
+    assert eng.sweep_plan_info(2, 63) == (32, 62)  # below 64: chains L, L/2, L/4, ... share one row-split pass (round 4)
     assert eng.qo_feasible(4096, np.float64, 512) and eng.qo_feasible(40000, np.float64, 512)  # long windows: HBM residual
     assert not eng.qo_feasible(4096, np.float64, 4096)  # beyond the row capacity of the workspace
 
