@@ -59,8 +59,10 @@ __device__ __forceinline__ double swizzle_xor4_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// All-reduce over the wavefront with the pairing of the classic xor butterfly (32, 16, 8, 4, 2, 1): every step adds
-// v[l] and v[l ^ o], so the result is bit-identical to a __shfl_xor loop.
+// All-reduce over the wavefront: half-waves and odd / even rows with permlane swaps, then DPP inside a row of 16 lanes
+// (ror 8, half mirror, xor 2, xor 1) -- nothing goes through the LDS pipe.  (Round 3 paired lanes as the classic xor
+// butterfly does and took the xor-4 step through ds_swizzle: an LDS-crossbar operation that queues behind the folds of
+// every other wavefront of the CU, on the critical path of every workgroup reduction.)
 template <bool MAXOP>
 __device__ __forceinline__ double wave_allreduce(double v) {
   auto op = [](double x, double y) { return MAXOP ? fmax(x, y) : x + y; };
@@ -77,7 +79,7 @@ __device__ __forceinline__ double wave_allreduce(double v) {
     v = op(__hiloint2double((int)r1[0], (int)r0[0]), __hiloint2double((int)r1[1], (int)r0[1]));
   }
   v = op(v, dpp_f64<kDppRor8>(v));
-  v = op(v, swizzle_xor4_f64(v));
+  v = op(v, dpp_f64<kDppHalfMirror>(v));  // (lane i + lane 7 - i of its group of 8: DPP, where round 3 went through ds_swizzle)
   v = op(v, dpp_f64<kDppXor2>(v));
   v = op(v, dpp_f64<kDppXor1>(v));
   return v;
@@ -131,6 +133,28 @@ __device__ __forceinline__ double block_sum_once(double v, double* red) {
   if ((tid & (kWave - 1)) == 0) red[tid >> 6] = v;
   __syncthreads();
   return uniform_f64(red_combine(red, nw));
+}
+
+// Workgroup argmax from the wave winners (value, period): largest value, lowest period among equals, period 0 = none.
+// All reads in flight before the comparisons, results in scalar registers (identical in every lane).
+__device__ __forceinline__ void red_argmax(const double* wbest, const int* wbestp, int nw, double& best, int& bestp) {
+  double v[kMaxWaves];
+  int p[kMaxWaves];
+#pragma unroll
+  for (int i = 0; i < kMaxWaves; ++i) {
+    v[i] = wbest[i];
+    p[i] = wbestp[i];
+  }
+  double b = 0.0;
+  int bp = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxWaves; ++i)
+    if (i < nw && p[i] != 0 && (v[i] > b || (v[i] == b && p[i] < bp))) {
+      b = v[i];
+      bp = p[i];
+    }
+  best = uniform_f64(b);
+  bestp = __builtin_amdgcn_readfirstlane(bp);
 }
 
 // sums of two values over the workgroup with one pair of barriers (every thread gets both)
@@ -312,6 +336,13 @@ __device__ __forceinline__ double block_sumsq(const T* __restrict__ v, int N, do
 // periodic_norm (Periods.py:221-241) from a sum of squares: (sqrt(ss)/sqrt(N)) [/sqrt(p)].
 __device__ __forceinline__ double periodic_norm_from_sq(double ss, int N, int p_div) {
   double v = sqrt(ss) / sqrt((double)N);
+  if (p_div > 0) v = v / sqrt((double)p_div);
+  return v;
+}
+// the same with sqrt(N) supplied (a scalar-register value of the caller: the compiler otherwise hoists the square root
+// into a vector register pair that lives -- and is spilled -- across the whole kernel)
+__device__ __forceinline__ double periodic_norm_from_sq_n(double ss, double sqrtN, int p_div) {
+  double v = sqrt(ss) / sqrtN;
   if (p_div > 0) v = v / sqrt((double)p_div);
   return v;
 }
@@ -939,7 +970,7 @@ __device__ __forceinline__ void wave_argmax(double& v, int& p) {
     take(v, p, __hiloint2double((int)r1[1], (int)r0[1]), (int)r2[1]);
   }
   take(v, p, dpp_f64<kDppRor8>(v), __builtin_amdgcn_update_dpp(0, p, kDppRor8, 0xF, 0xF, false));
-  take(v, p, swizzle_xor4_f64(v), __builtin_amdgcn_ds_swizzle(p, 0x101F));
+  take(v, p, dpp_f64<kDppHalfMirror>(v), __builtin_amdgcn_update_dpp(0, p, kDppHalfMirror, 0xF, 0xF, false));
   take(v, p, dpp_f64<kDppXor2>(v), __builtin_amdgcn_update_dpp(0, p, kDppXor2, 0xF, 0xF, false));
   take(v, p, dpp_f64<kDppXor1>(v), __builtin_amdgcn_update_dpp(0, p, kDppXor1, 0xF, 0xF, false));
 }

@@ -281,16 +281,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
         wbestp[wv] = bestp;
       }
       __syncthreads();
-      best = 0.0;
-      bestp = 0;
-      for (int i = 0; i < nw; ++i) {
-        const double v = wbest[i];
-        const int pp = wbestp[i];
-        if (pp != 0 && (v > best || (v == best && pp < bestp))) {
-          best = v;
-          bestp = pp;
-        }
-      }
+      red_argmax(wbest, wbestp, nw, best, bestp);
       __syncthreads();
     } else {
       for (int p = p_lo; p <= p_hi; ++p) {
@@ -465,11 +456,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
   double* prt = cv.take<double>(kPairSplitW);  // partial sums of split_row_means
 
   const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const size_t gstride = win_stride((size_t)N);
   float* pwf = reinterpret_cast<float*>(pw);
+  const double sqrtN = uniform_f64(sqrt((double)N));
 
   for (int k = tid; k < 2 * num; k += blockDim.x) {
     norms[k] = 0.0;
@@ -497,7 +488,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       dst2[2 + w] = sc;
       ctl[10 + w] = exists ? 1 : 0;
       ctl[12 + w] = pair_usable(rsq) ? 0 : 1;
-      if (exists) dnorm_out[gw] = periodic_norm_from_sq(rsq, N, 0);
+      if (exists) dnorm_out[gw] = periodic_norm_from_sq_n(rsq, sqrtN, 0);
     }
   }
 #ifdef PH_PAIR_TIMERS
@@ -519,10 +510,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
 #endif
   for (;;) {
     __syncthreads();
-    const bool act0 = ctl[10] != 0, act1 = ctl[11] != 0;
+    // (values that are identical in all lanes go to scalar registers as they are read: as vector registers they were
+    // spilled around the screen, and every reload is a scratch access through L2 on the critical path of the exact phases)
+    const bool act0 = __builtin_amdgcn_readfirstlane(ctl[10]) != 0, act1 = __builtin_amdgcn_readfirstlane(ctl[11]) != 0;
     if (!act0 && !act1) break;
-    prio_by_progress(max(ctl[8], ctl[9]));  // sweeps done: keeps the two workgroups of a CU in step (ph_device.h)
-    if (tid == 0) ctl[0] = ctl[1] = 0;  // (read as `ncand` before the last barrier of the previous round)
+    prio_by_progress(__builtin_amdgcn_readfirstlane(max(ctl[8], ctl[9])));  // sweeps done: keeps the two workgroups of a CU in step (ph_device.h)
+    if (wv == 0 && pair_lane() == 0) ctl[0] = ctl[1] = 0;  // (read as `ncand` before the last barrier of the previous round)
     // ---- 1. screen of both windows (Periods.py:501-515 in float); values into the idle staging buffer
     f2* vals = reinterpret_cast<f2*>(stg);
     pair_sweep_plan(
@@ -537,12 +530,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     __syncthreads();
     PH_PAIR_MARK(0)
     prio_short_phase();
+    {  // phases 2 and 3 of this round
+    // The thread and lane indices are RECOMPUTED here (wave number in a scalar register + v_mbcnt): kept live across the
+    // screen they were spilled, and the exact phases reloaded them from scratch -- through L2 -- fifteen times per round.
+    const int tid = (wv << 6) + pair_lane();
+    const int lane = tid & (kWave - 1);
     if (tid == 0) ctl[14] = nw;  // the pass queue of the next screen (barriers in between)
     // ---- 2. survivors of both windows: two passes over the values (a thread sees the same <= 2 entries twice)
     {
-      const bool scr0 = act0 && !ctl[12], scr1 = act1 && !ctl[13];
+      const bool scr0 = act0 && !__builtin_amdgcn_readfirstlane(ctl[12]), scr1 = act1 && !__builtin_amdgcn_readfirstlane(ctl[13]);
       if (scr0 || scr1) {
-        const double unit0 = dst2[0], unit1 = dst2[1];
+        const double unit0 = uniform_f64(dst2[0]), unit1 = uniform_f64(dst2[1]);
         double lo0 = -1.0 / 0.0, lo1 = -1.0 / 0.0;
         for (int idx = tid; idx < P; idx += blockDim.x) {
           const int q = p_lo + idx;
@@ -565,12 +563,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
           red[kMaxWaves + wv] = lo1;
         }
         __syncthreads();
-        lo0 = red[0];
-        lo1 = red[kMaxWaves];
-        for (int i = 1; i < nw; ++i) {
-          lo0 = fmax(lo0, red[i]);
-          lo1 = fmax(lo1, red[kMaxWaves + i]);
-        }
+        lo0 = uniform_f64(red_combine<true>(red, nw));
+        lo1 = uniform_f64(red_combine<true>(red + kMaxWaves, nw));
         // periods that tie with the winner in the ROUNDED norm survive too
         const double thr0 = lo0 - fabs(lo0) * 1e-9, thr1 = lo1 - fabs(lo1) * 1e-9;
         for (int idx = tid; idx < P; idx += blockDim.x) {
@@ -601,9 +595,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     for (int w = 0; w < 2; ++w) {
       if (!(w ? act1 : act0)) continue;
       const int64_t gw = 2 * (int64_t)blockIdx.x + w;
-      int filled = ctl[2 + w], repeats = ctl[4 + w], status = 0, iters = ctl[8 + w];
-      const bool exact_all = ctl[12 + w] != 0 || ctl[w] > kPairListCap;
-      const int ncand = exact_all ? P : ctl[w];
+      int filled = __builtin_amdgcn_readfirstlane(ctl[2 + w]), repeats = __builtin_amdgcn_readfirstlane(ctl[4 + w]), status = 0,
+          iters = __builtin_amdgcn_readfirstlane(ctl[8 + w]);
+      const int nlisted = __builtin_amdgcn_readfirstlane(ctl[w]);
+      const bool exact_all = __builtin_amdgcn_readfirstlane(ctl[12 + w]) != 0 || nlisted > kPairListCap;
+      const int ncand = exact_all ? P : nlisted;
       double* nrm = norms + w * num;
       uint32_t* per = periods + w * num;
       uint32_t* sk = skip + w * SK;
@@ -633,8 +629,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
             if (lhs > rhs * (1.0 + 1e-14)) {
               take = true;
             } else if (lhs >= rhs * (1.0 - 1e-14)) {
-              const double vn = periodic_norm_from_sq(ss, N, gamma ? p : 0);
-              const double vb = periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0);
+              const double vn = periodic_norm_from_sq_n(ss, sqrtN, gamma ? p : 0);
+              const double vb = periodic_norm_from_sq_n(best_ss, sqrtN, gamma ? bestp : 0);
               take = vn > vb || (vn == vb && p < bestp);
             }
           }
@@ -659,7 +655,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
             }
             consider(block_sum(part, red), p);
           }
-          best = bestp != 0 ? periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0) : 0.0;
+          best = bestp != 0 ? periodic_norm_from_sq_n(best_ss, sqrtN, gamma ? bestp : 0) : 0.0;
           if (!(best > 0.0)) bestp = 0;  // the reference needs p_norm > 0 (Periods.py:497,512)
         } else {
           for (int k = wv; k < ncand; k += nw) {
@@ -669,23 +665,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
             const double part = p < 64 ? wave_partial_small(stg, N, p, g, lane) : pair_exact_part(stg, p, g, lane, kWave);
             consider(wave_sum(part), p);
           }
-          best = bestp != 0 ? periodic_norm_from_sq(best_ss, N, gamma ? bestp : 0) : 0.0;
+          best = bestp != 0 ? periodic_norm_from_sq_n(best_ss, sqrtN, gamma ? bestp : 0) : 0.0;
           if (!(best > 0.0)) bestp = 0;
           if (lane == 0) {
             wbest[wv] = best;
             wbestp[wv] = bestp;
           }
           __syncthreads();
-          best = 0.0;
-          bestp = 0;
-          for (int i = 0; i < nw; ++i) {
-            const double v = wbest[i];
-            const int pp = wbestp[i];
-            if (pp != 0 && (v > best || (v == best && pp < bestp))) {
-              best = v;
-              bestp = pp;
-            }
-          }
+          red_argmax(wbest, wbestp, nw, best, bestp);
           __syncthreads();
         }
         PH_PAIR_MARK(3)
@@ -721,7 +708,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
           // float image only has to keep the RMS near 1; it is renewed when the residual has shrunk by 2^16.
           double* brow = rows_out + (gw * (int64_t)num + (row < 0 ? 0 : row)) * row_stride;
           const bool more = filled < num;
-          const double sc = dst2[2 + w];
+          const double sc = uniform_f64(dst2[2 + w]);
           double* dst = gres + gw * gstride;
           double acc = 0.0;
           const Fold f(N, bestp);
@@ -798,6 +785,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       }
       PH_PAIR_MARK(4)
     }
+    }  // phases 2 and 3
   }
 #ifdef PH_CLOCKS
   if ((blockIdx.x % 16) == 7 && tid == 0) {
@@ -1460,16 +1448,7 @@ __global__ __launch_bounds__(kBlockWide) __attribute__((amdgpu_waves_per_eu(PH_S
         wbestp[wv] = bestp;
       }
       __syncthreads();
-      best = 0.0;
-      bestp = 0;
-      for (int k = 0; k < nw; ++k) {
-        const double v = wbest[k];
-        const int pp = wbestp[k];
-        if (pp != 0 && (v > best || (v == best && pp < bestp))) {
-          best = v;
-          bestp = pp;
-        }
-      }
+      red_argmax(wbest, wbestp, nw, best, bestp);
       __syncthreads();
       if (bestp == 0) {
         status = 1;  // reference: project(data, None) raises
@@ -1675,16 +1654,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
           wbestp[wv] = bestp;
         }
         __syncthreads();
-        best = 0.0;
-        bestp = 0;
-        for (int k = 0; k < nw; ++k) {
-          const double v = wbest[k];
-          const int pp = wbestp[k];
-          if (pp != 0 && (v > best || (v == best && pp < bestp))) {
-            best = v;
-            bestp = pp;
-          }
-        }
+        red_argmax(wbest, wbestp, nw, best, bestp);
         __syncthreads();
         if (bestp == 0) {
           status = 1;  // reference: project(data, None) raises
@@ -2763,16 +2733,7 @@ __global__ __launch_bounds__(1024) PH_QO_OCC void k_qo_find(const T* __restrict_
       wbestp[wv] = bestp;
     }
     __syncthreads();
-    best = 0.0;
-    bestp = 0;
-    for (int i = 0; i < nw; ++i) {
-      const double v = wbest[i];
-      const int pp = wbestp[i];
-      if (pp != 0 && (v > best || (v == best && pp < bestp))) {
-        best = v;
-        bestp = pp;
-      }
-    }
+    red_argmax(wbest, wbestp, nw, best, bestp);
     __syncthreads();
     PH_QO_MARK(0)
     if (bestp == 0) break;  // nothing left to explain; the reference keeps looping on zeros

@@ -41,6 +41,7 @@ namespace ph {
 // 1e-10 bar, only Periods.project itself (ph_project_batch) is held to bit-identity -- and np.linalg.norm has no
 // defined order anyway.  Threads >= width do nothing; msm holds >= width elements.
 // `part` (>= width elements) takes the partial sums of split_row_means; it may be `msm` itself (one more barrier then).
+constexpr int kFlatBatch = 8;  // samples a thread takes per trip of the flat loops (N = 4096, 512 threads: one trip)
 struct S2LNoMark {
   __device__ __forceinline__ void operator()(int) const {}
 };
@@ -51,13 +52,25 @@ __device__ __forceinline__ double s2l_flat_trial(const T* __restrict__ work, T* 
   mark(4);
   double tsq = 0.0;
   if (tid < width) {
+    // kFlatBatch samples per trip with all their LDS reads in flight before the first is used (a rolled loop paid one
+    // LDS round trip per sample: 8 of them at N = 4096); the additions keep the order n = tid, tid + width, ...
     int idx = tid % p;
     const int step = width % p;
-    for (int n = tid; n < N; n += width) {
-      const double t = (double)(work[n] - msm[idx]);
-      tsq = fma(t, t, tsq);
-      idx += step;
-      idx = idx >= p ? idx - p : idx;
+    for (int n0 = tid; n0 < N; n0 += kFlatBatch * width) {
+      T x[kFlatBatch], m[kFlatBatch];
+#pragma unroll
+      for (int k = 0; k < kFlatBatch; ++k) {
+        const int n = n0 + k * width;
+        x[k] = work[n < N ? n : n0];
+        m[k] = msm[idx];
+        idx += step;
+        idx = idx >= p ? idx - p : idx;
+      }
+#pragma unroll
+      for (int k = 0; k < kFlatBatch; ++k) {
+        const double t = (double)(x[k] - m[k]);
+        tsq = n0 + k * width < N ? fma(t, t, tsq) : tsq;
+      }
     }
   }
   return tsq;
@@ -71,14 +84,26 @@ __device__ __forceinline__ void s2l_flat_update(T* __restrict__ work, const T* _
   if (tid >= width) return;
   int idx = tid % p;
   const int step = width % p;
-  for (int n = tid; n < N; n += width) {
-    const T m = msm[idx];
-    const T v = work[n] - m;
-    if (brow) brow[n] = m;
-    work[n] = v;
-    extra(n, v);
-    idx += step;
-    idx = idx >= p ? idx - p : idx;
+  for (int n0 = tid; n0 < N; n0 += kFlatBatch * width) {  // batched like s2l_flat_trial
+    T x[kFlatBatch], m[kFlatBatch];
+#pragma unroll
+    for (int k = 0; k < kFlatBatch; ++k) {
+      const int n = n0 + k * width;
+      x[k] = work[n < N ? n : n0];
+      m[k] = msm[idx];
+      idx += step;
+      idx = idx >= p ? idx - p : idx;
+    }
+#pragma unroll
+    for (int k = 0; k < kFlatBatch; ++k) {
+      const int n = n0 + k * width;
+      if (n < N) {
+        const T v = x[k] - m[k];
+        if (brow) brow[n] = m[k];
+        work[n] = v;
+        extra(n, v);
+      }
+    }
   }
 }
 
@@ -111,7 +136,15 @@ __device__ __forceinline__ void s2l_copy(const double* __restrict__ src, double*
   if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (N & 1) == 0) {
     const double2* s = reinterpret_cast<const double2*>(src);
     double2* d = reinterpret_cast<double2*>(dst);
-    for (int i = threadIdx.x; i < N / 2; i += blockDim.x) d[i] = s[i];
+    const int nv = N / 2, bd = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nv; i0 += 4 * bd) {  // four loads in flight per thread: one L2 round trip at N = 4096
+      double2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = s[i0 + k * bd < nv ? i0 + k * bd : i0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * bd < nv) d[i0 + k * bd] = v[k];
+    }
   } else {
     for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = src[i];
   }
@@ -233,7 +266,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     had_event = false;
     prio_long_phase();
     {
-      const float t00 = thf[0], t01 = thf[1], t10 = thf[2], t11 = thf[3];
+      const float t00 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(thf[0]))),
+                  t01 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(thf[1]))),
+                  t10 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(thf[2]))),
+                  t11 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(thf[3])));
       int q = start + wv;
       for (;;) {
         const int lim = __builtin_amdgcn_readfirstlane(*(volatile int*)&qc[S2L_LIMIT]);
@@ -272,8 +308,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #endif
     prio_short_phase();
     // every ticket below `front` was executed; a flag at or beyond it is not known to be the window's first
-    const int front = min(qc[S2L_SKIP], qc[S2L_TICK]);
-    int c0 = qc[S2L_STOP0], c1 = qc[S2L_STOP1];
+    // (the events below run beside the other workgroup's screen, whose folds keep the LDS queue of the CU full: an LDS
+    // round trip costs several hundred cycles here, so everything an event needs from LDS is read in this one batch)
+    // Everything read here is identical in all lanes and goes to SCALAR registers at once: as vector registers these
+    // values (and the positions, owner and flags derived from them) were spilled around the screen loop, and every
+    // reload is a scratch access through L2 -- a dozen of them sat on the critical path of an event.
+    const int front = __builtin_amdgcn_readfirstlane(min(qc[S2L_SKIP], qc[S2L_TICK]));
+    int c0 = __builtin_amdgcn_readfirstlane(qc[S2L_STOP0]), c1 = __builtin_amdgcn_readfirstlane(qc[S2L_STOP1]);
+    const double st_rn0 = uniform_f64(st[2]), st_rn1 = uniform_f64(st[3]), st_dn0 = uniform_f64(st[4]), st_dn1 = uniform_f64(st[5]),
+                 st_sc0 = uniform_f64(st[6]), st_sc1 = uniform_f64(st[7]);
+    const int st_cnt0 = __builtin_amdgcn_readfirstlane(ct[0]), st_cnt1 = __builtin_amdgcn_readfirstlane(ct[1]);
     if (c0 >= front) c0 = kS2LInf;
     if (c1 >= front) c1 = kS2LInf;
     // ---- exact evaluation of each window's candidate (Periods.py:274-286); the owner of the staging buffer first
@@ -304,8 +348,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         __syncthreads();
       }
       had_event = true;
-      const double rn = st[2 + w], dn = st[4 + w], sc = st[6 + w];
-      const int count = ct[w];
+      const double rn = w ? st_rn1 : st_rn0, dn = w ? st_dn1 : st_dn0, sc = w ? st_sc1 : st_sc0;
+      const int count = w ? st_cnt1 : st_cnt0;
       const Fold f(N, cand);
       double tsq = 0.0;
       const bool flat = cand <= kEx;  // means through LDS, sums and update flat over the samples (s2l_flat_trial)
@@ -410,7 +454,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   }
   if (tid == 0) qc[6] = (int)gridDim.x + atomicAdd(next_pair, 1);  // the host zeroes the counter before the launch
   __syncthreads();
-  pair = qc[6];
+  pair = __builtin_amdgcn_readfirstlane(qc[6]);
   }  // pairs
 }
 
