@@ -252,8 +252,8 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the config-4 leg")
     ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 leg")
     ap.add_argument("--c4-windows", type=int, default=C4_WINDOWS, help="rehearsals only; the reported config is 65536")
-    ap.add_argument("--pieces", default="1,3", help="N>1: how the scatter of each rank's block is cut: a count of equal pieces "
-                    "or comma-separated weights (default 1,3: a quarter first, then the rest -- pyperiod_amd/dist.py piece_rows)")
+    ap.add_argument("--pieces", default="2", help="N>1: how the scatter of each rank's block is cut: a count of equal pieces "
+                    "(default 2) or comma-separated weights, e.g. 1,3 (pyperiod_amd/dist.py piece_rows)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -111,9 +111,10 @@ def run_sharded(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, to
 
 def piece_rows(per: int, pieces) -> list[int]:
     """Rows of the pieces a block of `per` windows is cut into.  `pieces` is a count (equal pieces) or a sequence of
-    weights: (1, 3) = a first piece of a quarter of the block -- the only scatter no kernel hides -- and one launch for
-    the rest.  Every launch ends with a partly empty chip, so fewer and larger pieces compute faster (tools/s2l_scale.py:
-    one 8192-window launch of small_to_large 5.5 ms, two pieces 5.6, four pieces 6.2-6.7)."""
+    weights, e.g. (1, 3) = a first piece of a quarter of the block and one launch for the rest.  Every launch ends with a
+    partly empty chip and a small piece is mostly tail, so fewer and larger pieces compute faster (tools/s2l_scale.py, one
+    rank's 8192-window block of config 4: one launch of small_to_large 5.5 ms, two halves 5.55, a quarter + the rest
+    6.0, four quarters 6.2-6.6); the first piece's scatter is the only one no kernel hides."""
     if isinstance(pieces, int):
         n = max(1, min(int(pieces), max(per, 1)))
         step = -(-per // n)
@@ -130,7 +131,7 @@ def piece_rows(per: int, pieces) -> list[int]:
 
 
 def run_sharded_pipelined(fn: Callable[[torch.Tensor], Sequence[torch.Tensor]], x_root, total: int, n: int, dtype,
-                          device, pieces=(1, 3), root: int = 0, group=None):
+                          device, pieces=2, root: int = 0, group=None):
     """Like run_sharded, with the scatter cut into pieces (`piece_rows`) -- one asynchronous collective per piece and
     rank: all of them are enqueued up front (RCCL runs them on its own stream, in order), and `fn` runs on piece k as
     soon as it has landed while the later pieces are still in flight.  Results are concatenated per rank and gathered

@@ -73,8 +73,8 @@ def pieces_weighted(weights):
 
 
 a = timed(lambda: pieces_weighted((1, 3)))
-print(f"shard as run_sharded_pipelined issues it by default (pieces (1, 3): 2048 + 6144 windows): {a:6.3f} ms ({full / a:5.2f}x)")
-for n in (2, 4, 8):
+print(f"shard as pieces (1, 3): 2048 + 6144 windows: {a:6.3f} ms ({full / a:5.2f}x)")
+for n in (2, 4, 8):  # 2 = what run_sharded_pipelined issues by default
     a = timed(lambda: pieces_one_stream(n))
     b = timed(lambda: pieces_two_streams(n))
     print(f"shard as {n} pieces: one stream {a:6.3f} ms ({full / a:5.2f}x)   two alternating streams {b:6.3f} ms ({full / b:5.2f}x)")
