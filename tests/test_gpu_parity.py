@@ -553,3 +553,26 @@ def test_project_float32_trunc_keeps_float32_like_the_reference(golden):
                     assert np.array_equal(got, want), (n, p)  # the same float32 operations in the same order
                 worst = max(worst, rel_err(got, want))
     assert worst < 5e-7  # orth: float32 subtractions of float32 projections, same order up to fused rounding
+
+
+def test_sweep_ranges_that_cut_the_chains_of_short_periods(eng):
+    """ph_sweep's norm modes take the periods up to 64 in chains L, L/2, L/4, ... (one row-split pass each,
+    wave_chain_small, round 4): ranges that start inside a chain, end below 64, hold a single short period, or straddle 64
+    must give the oracle's norms (Periods.py:501-510), for windows with strong short-period components and for lengths
+    whose folds are ragged."""
+    rng = np.random.default_rng(5)
+    for n in (4096, 1000, 97):
+        t = np.arange(n)
+        x = np.stack([3.0 * rng.standard_normal(6)[t % 6] + 2.0 * rng.standard_normal(48)[t % 48] +
+                      1.5 * rng.standard_normal(35)[t % 35] + 0.2 * rng.standard_normal(n) for _ in range(3)])
+        for lo, hi in ((2, 64), (2, 63), (2, 50), (5, 64), (7, 40), (13, 13), (33, 100), (48, 96), (3, 24), (64, 200), (17, 300), (1, 70)):
+            if hi > n:
+                continue
+            for mode in (0, 1):
+                got = eng.sweep(x, lo, hi, mode)
+                for w in range(3):
+                    want = po.sweep_norms(x[w], lo, hi, gamma=(mode == 1))
+                    s = slice(1, None) if lo == 1 else slice(None)  # p = 1: numpy sums the contiguous axis pairwise (DESIGN 3)
+                    assert elem_err(got[w][s], want[s]) < TOL, (n, lo, hi, mode, w)
+                    if lo == 1:
+                        assert abs(got[w][0] - want[0]) <= 1e-13 * max(1.0, abs(want[0]))
