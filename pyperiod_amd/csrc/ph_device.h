@@ -246,11 +246,16 @@ __device__ __forceinline__ T residue_mean(const T* __restrict__ xs, const Fold& 
 // `part` holds >= G p <= width elements and may be `msm` itself (one more barrier then); ends with a barrier: on
 // return msm[0 .. p) is complete for every thread.  Threads >= width take no part.
 constexpr int kSplitMax = 64;
+constexpr int kSplitMinRows = 32;  // rows a residue must have before they are dealt to several threads (>= 16 per thread)
 template <typename T>
 __device__ __forceinline__ void split_row_means(const T* __restrict__ work, T* msm, T* part, int N, int p, int tid, int width) {
   const int rows = (N + p - 1) / p, nfull = p - (rows * p - N);  // Fold(N, p)
+  // Residues with fewer than kSplitMinRows rows keep the row order (a chain that short costs nothing, and windows of a
+  // few dozen samples -- where a last pick of m_best can hang on whether a residual is EXACTLY zero -- then project
+  // bit for bit like the reference).
   int G = 1;
-  while (2 * G * p <= width && G < kSplitMax) G <<= 1;
+  if (rows >= kSplitMinRows)
+    while (2 * G * p <= width && G < kSplitMax && rows >= 2 * G * (kSplitMinRows / 2)) G <<= 1;
   if (G == 1) {
     if (tid < width)
       for (int j = tid; j < p; j += width) {
