@@ -7,7 +7,13 @@ import numpy as np
 from oracle import period_oracle as po
 from pyperiod_amd import default_engine, _ffi
 from pyperiod_amd.synth import multi_sinusoid_batch
-eng = default_engine()
+class _Dry:  # FUZZ_DRY=1: no GPU -- every engine call raises, so a trial only consumes its random draws (all of them come
+    def __getattr__(self, name):  # before the engine call): the sequence of requests of a seed can be replayed on the CPU
+        def f(*a, **k): raise RuntimeError("dry")
+        return f
+DRY = bool(os.environ.get("FUZZ_DRY"))
+FIND = tuple(int(v) for v in os.environ["FUZZ_FIND"].split(",")) if os.environ.get("FUZZ_FIND") else None  # n,num,max_length of an m_best request to save
+eng = _Dry() if DRY else default_engine()
 TOL = 1e-10
 def rel(a, b):
     a = np.asarray(a, float); b = np.asarray(b, float)
@@ -41,13 +47,21 @@ while time.time() < t_end:
                 if rel(got[i][s], want[s]) > TOL: bad += 1; print("SWEEP", n, lo, hi, mode, rel(got[i][s], want[s]))
         elif which == 1 and n >= 12:
             num = int(rng.integers(1, 8)); gamma = bool(rng.integers(0, 2)); ml = int(rng.integers(3, max(4, n//2 if rng.integers(0, 4) else min(n - 1, 700))))
+            if FIND and (n, num, ml) == FIND:
+                np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_find_{n}_{num}_{ml}_{int(gamma)}.npy"), x); print("FOUND", trials, n, num, ml, gamma, flush=True)
             per, pw, bs, st = eng.m_best(x, num, ml, 2, gamma)
             for i in range(w):
                 tr = {}
                 try: r = po.m_best(x[i], num, ml, 2, gamma, trace=tr)
                 except Exception: r = None
                 if r is None:
-                    if st[i] == 0: bad += 1; print("MBEST status", n, num, ml, gamma)
+                    # The reference ran out of candidates (Periods.py:520 raises): every remaining norm is EXACTLY zero there.
+                    # On exactly representable data (the grid generator) the device's sweep, which adds in another order,
+                    # can see 1e-17 instead of 0 and make one more pick at rounding-noise level -- the same class as the
+                    # noise-level picks below, recognised here by the device's own weakest power.
+                    if st[i] == 0:
+                        if np.min(np.abs(pw[i])) < 1e-10 * np.max(np.abs(pw[i])): noise += 1
+                        else: bad += 1; print("MBEST status", n, num, ml, gamma)
                     continue
                 s1 = np.abs(tr["step1_norms"])
                 if min(np.min(np.abs(r[1])), np.min(s1) / po.periodic_norm(x[i])) < 1e-10 * np.max(np.abs(r[1])) or tr["step1_min_gap"] < 1e-12:
@@ -154,5 +168,5 @@ while time.time() < t_end:
             r = po.m_best(xl[0], 2, hi)
             if not np.array_equal(per[0], r[0]) or rel(pw[0], r[1]) > TOL: bad += 1; print("LMBEST", nl, hi, per[0], r[0])
     except Exception as exc:
-        bad += 1; print("EXC", which, n, repr(exc)[:200])
+        if not DRY: bad += 1; print("EXC", which, n, repr(exc)[:200])
 print("trials", trials, "mismatches", bad, "m_best noise-level requests skipped", noise)
