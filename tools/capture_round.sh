@@ -9,6 +9,9 @@ bash tools/profile_all.sh "$T" > "$R/gpurun_out/${T}_capture.log" 2>&1 || { tail
 python3 tools/profile_table.py "$O" --md --merge profiles/traffic.json --source "profiles/$T/pmc_summary.csv" > "$O/table.md"
 cp profiles/traffic.json "$O/traffic_merged.json"
 echo "capture done"
+# bench.py may ONLY be profiled with --kernel-trace / --stats: it spawns pool workers and may start hipcc, and with --pmc the
+# profiler's preloaded library initialises the GPU first, which turns those spawns into exec-after-GPU-init (refused on the GPU
+# boxes).  Counter passes use tools/profile_all.py / s2l_pmc.py / ram_pmc.py, which spawn nothing.
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench_trace" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_rocprof_line.json" 2> "$O/bench_rocprof.err" )
 find "$O/bench_trace" -name "*kernel_stats.csv" -exec cp {} "$O/bench_rocprof_kernel_stats.csv" \;
 rm -rf "$O/bench_trace"
