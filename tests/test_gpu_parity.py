@@ -212,6 +212,25 @@ def test_m_best_exhausted_range_boundary(eng):
         assert rel_err(pw[0], rpw) < TOL and rel_err(bs[0], rbs) < TOL, seed
 
 
+def test_m_best_reference_runs_out_of_candidates_on_an_exact_zero(eng):
+    """The mirror image of the limit above (found by tools/fuzz_gpu.py, seed 9107): 18 quarter-integer samples, num = 4,
+    max_length = 5.  Periods 3, 4 and 5 are picked, repeated and blacklisted; the projection onto 2 (contained in the one
+    onto 4) is rounding noise by then -- 1e-17 in most sweeps, EXACTLY zero in the reference's order of additions at the
+    sweep that matters, so the reference finds no candidate and raises (Periods.py:520).  The device adds in another
+    order: it may report the same failure or make a fourth pick at rounding-noise level; the three real picks must be
+    the reference's either way (asking for three periods agrees bit for bit)."""
+    x = np.array([1.25, -0.75, -0.5, -0.75, -0.5, 0.75, -2.0, 1.0, 0.75, -0.25, -0.25, -0.25, 1.0, 0.0, -0.75, 1.0, 0.75, -0.5])
+    with pytest.raises(Exception):
+        po.m_best(x, 4, 5, 2, False)
+    rper, rpw, rbs = po.m_best(x, 3, 5, 2, False)
+    per3, pw3, bs3, st3 = eng.m_best(x[None, :], 3, 5, 2, False)
+    assert st3[0] == 0 and np.array_equal(per3[0], rper)
+    assert rel_err(pw3[0], rpw) < TOL and rel_err(bs3[0], rbs) < TOL
+    per, pw, bs, st = eng.m_best(x[None, :], 4, 5, 2, False)
+    if st[0] == 0:
+        assert np.min(np.abs(pw[0])) < 1e-10 * np.max(np.abs(pw[0]))  # the fourth pick is noise, and its power says so
+
+
 def test_m_best_periods_beyond_two_thirds_of_the_window(eng, golden):
     """max_length well above the default N/3 (reference fixture `m_best_large_p`): rows whose period exceeds
     2N/3 take step 2's tiled-row path (the compact p-vector plus its zero row no longer fits the row buffer;
