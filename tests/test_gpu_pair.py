@@ -241,6 +241,35 @@ def test_small_to_large_pair_kernel_equals_one_window_kernel():
         pair.close()
 
 
+def test_small_to_large_pair_kernel_with_eight_wavefronts():
+    """PH_S2L_BLOCK=512 (a tuning knob): the queue kernel with 8 wavefronts per pair -- the exact phases then use every
+    thread and the bookkeeping falls to thread 0 -- must return what the 16-wave launch returns, bit for bit."""
+    import __graft_entry__ as ge
+
+    ge.build()
+    from pyperiod_amd import PeriodEngine
+
+    wide = PeriodEngine(0)
+    old = os.environ.get("PH_S2L_BLOCK")
+    os.environ["PH_S2L_BLOCK"] = "512"
+    narrow = PeriodEngine(0)
+    if old is None:
+        del os.environ["PH_S2L_BLOCK"]
+    else:
+        os.environ["PH_S2L_BLOCK"] = old
+    try:
+        for n, w, thresh in ((4096, 33, 0.05), (2000, 5, 0.1), (97, 2, 0.01)):
+            x = multi_sinusoid_batch(500 + n, w, n)
+            a = wide.small_to_large(x, thresh, None, cap=64)
+            b = narrow.small_to_large(x, thresh, None, cap=64)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+            for i, k in enumerate(a[0]):
+                assert np.array_equal(a[3][i, :k], b[3][i, :k])
+    finally:
+        wide.close()
+        narrow.close()
+
+
 def test_best_correlation_pair_kernel_equals_one_window_kernel():
     """k_best_correlation_pair against the one-window kernel (PH_BC_PAIR=0) and the oracle: periods, norm gains and
     bases -- odd batches, lengths with ragged folds, a ratio that rejects some picks (zero rows), a zero window."""
