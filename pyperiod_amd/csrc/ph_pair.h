@@ -251,6 +251,71 @@ __device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, 
   }
 }
 
+// ---------------------------------------------------------------- single-period pass with one dispatch
+// pair_pass_seg<1> walks its two segments in a loop and chooses the code of each by its row count: per segment a
+// dozen scalar selects, a compare chain and the flags of the fall-through, ~60 scalar instructions per pass before
+// the first load -- and one CU has ONE scalar unit for its 32 wavefronts (tools/micro/valu_rate.hip: 1.05 cycles per
+// s_add_u32 per CU), which the screens keep ~90 % busy.  Here the pass is dispatched once, on the row count of the
+// period, to straight-line code for both segments.
+template <int NR, bool MX>
+__device__ __forceinline__ f2 pair_single_rows(pair_ptr base, int p, int len, int lane) {
+  constexpr int CG = NR <= 4 ? 4 : 2;
+  f2 part = f2_zero();
+  const int whole = len >> 6;
+  int c = 0;
+  for (; c + CG <= whole; c += CG) pair_rows_group<NR, CG, false, MX>(base + 64 * c, p, 0, lane, part);
+  for (; c < whole; ++c) {
+    asm volatile("" ::: "memory");
+    pair_rows_group<NR, 1, false, MX>(base + 64 * c, p, 0, lane, part);
+  }
+  const int rem = len & 63;
+  if (rem) {
+    asm volatile("" ::: "memory");
+    pair_rows_group<NR, 1, true, MX>(base + 64 * whole, p, rem, lane, part);
+  }
+  return part;
+}
+
+template <bool MX>
+__device__ __forceinline__ f2 pair_single_general(pair_ptr base, int p, int len, int nrows, int lane) {
+  f2 part[3] = {f2_zero(), f2_zero(), f2_zero()};
+  const float wgt[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  const int whole = len >> 6;
+  int c = 0;
+  for (; c + 4 <= whole; c += 4) pair_seg_group<1, 2, 4, false, MX>(base + 64 * c, p, nrows, 256, lane, wgt, part);
+  const int left = len - 64 * c;  // < 256 columns
+  if (left > 128) {
+    if (left > 192) pair_seg_group<1, 2, 4, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    else pair_seg_group<1, 2, 3, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+  } else if (left > 0) {
+    if (left > 64) pair_seg_group<1, 2, 2, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    else pair_seg_group<1, 2, 1, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+  }
+  return part[0];
+}
+
+// Per-lane partials of sum_j S_p[j]^2 / cnt_p[j] (MX: max_j S_p[j]^2) of both windows, p >= 64
+template <bool MX = false>
+__device__ __forceinline__ f2 pair_pass_single(const f2* __restrict__ xs, int p, const PGeomF g) {
+  const int lane = pair_lane();
+  const pair_ptr a = (pair_ptr)xs + lane, b = a + g.nfull;
+  const int cut = g.nfull, rest = p - cut;
+  f2 sa, sb;
+  switch (g.rows) {
+    case 2: sa = pair_single_rows<2, MX>(a, p, cut, lane); sb = pair_single_rows<1, MX>(b, p, rest, lane); break;
+    case 3: sa = pair_single_rows<3, MX>(a, p, cut, lane); sb = pair_single_rows<2, MX>(b, p, rest, lane); break;
+    case 4: sa = pair_single_rows<4, MX>(a, p, cut, lane); sb = pair_single_rows<3, MX>(b, p, rest, lane); break;
+    case 5: sa = pair_single_rows<5, MX>(a, p, cut, lane); sb = pair_single_rows<4, MX>(b, p, rest, lane); break;
+    case 6: sa = pair_single_rows<6, MX>(a, p, cut, lane); sb = pair_single_rows<5, MX>(b, p, rest, lane); break;
+    default:
+      sa = pair_single_general<MX>(a, p, cut, g.rows, lane);
+      sb = pair_single_general<MX>(b, p, rest, g.rows - 1, lane);
+      break;
+  }
+  if (MX) return f2_max(sa, sb);
+  return f2_fma(sa, f2_make(g.w_full, g.w_full), sb * g.w_short);
+}
+
 // p < 64: row-split path of wave_fold_small / wave_partial_small for pairs.
 template <bool MX = false>
 __device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int N, int p, const PGeomF& g) {
@@ -477,9 +542,7 @@ __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N
     } else if (m == 0) {
       consume(red(pair_partial_small<MX>(xs, N, p, geom[p])), p);
     } else if (m == 1) {
-      f2 part[3];
-      pair_pass_seg<1, MX>(xs, p, geom, part);
-      consume(red(part[0]), p);
+      consume(red(pair_pass_single<MX>(xs, p, geom[p])), p);
     } else if (m == 2) {
       f2 part[3];
       pair_pass_seg<2, MX>(xs, p, geom, part);

@@ -112,6 +112,17 @@ constexpr int kStampCap = 65536;
 __device__ long long g_ph_stamps[4 * kStampCap];  // diagnostic build only (tools/s2l_clocks.py)
 #endif
 constexpr int kS2LInf = 0x7fffffff;
+typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
+
+// ds_add_rtn_u32 by the calling lane: `atomicAdd` on LDS goes through the compiler's atomic optimiser, which wraps the one
+// active lane's add into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane, v_add)
+__device__ __forceinline__ int lds_ticket(int* counter) {
+  int old;
+  const __attribute__((address_space(3))) int* p = (const __attribute__((address_space(3))) int*)counter;
+  const int one = 1;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(p), "v"(one) : "memory");
+  return old;  // (the caller's readfirstlane waits for lgkmcnt)
+}
 enum { S2L_TICK = 0, S2L_LIMIT, S2L_STOP0, S2L_STOP1, S2L_SKIP, S2L_QWORDS = 8 };
 
 // LDS of one workgroup (host and device agree through this one function)
@@ -272,22 +283,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                   t11 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(thf[3])));
       int q = start + wv;
       for (;;) {
-        const int lim = __builtin_amdgcn_readfirstlane(*(volatile int*)&qc[S2L_LIMIT]);
+        const int lim = __builtin_amdgcn_readfirstlane(*(lds_int_ptr)&qc[S2L_LIMIT]);  // (a plain `volatile int*` became a flat load)
         if (q > lim) {
           if (q <= n_periods && pair_lane() == 0) atomicMin(&qc[S2L_SKIP], q);
           break;
         }
         int nxt = 0;
-        if (pair_lane() == 0) nxt = atomicAdd(&qc[S2L_TICK], 1);  // the next ticket: claimed now, looked at after this pass
+        if (pair_lane() == 0) nxt = lds_ticket(&qc[S2L_TICK]);  // the next ticket: claimed now, looked at after this pass
         const float kap = kapf[q];
-        f2 v;
-        if (q >= 64) {
-          f2 part[3];
-          pair_pass_seg<1>(pw, q, geomf, part);
-          v = pair_wave_sum(part[0]);
-        } else {
-          v = pair_wave_sum(pair_partial_small(pw, N, q, geomf[q]));
-        }
+        const PGeomF gq = geomf[q];
+        const f2 v = pair_wave_sum(q >= 64 ? pair_pass_single(pw, q, gq) : pair_partial_small(pw, N, q, gq));
         const bool f0 = q >= pos0 && !(v.x <= fmaf(-t01, kap, t00));  // NaN -> evaluate
         const bool f1 = q >= pos1 && !(v.y <= fmaf(-t11, kap, t10));
         if ((f0 || f1) && pair_lane() == 0) {
@@ -296,6 +301,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           atomicMin(&qc[S2L_LIMIT], q);
         }
         q = __builtin_amdgcn_readfirstlane(nxt);
+#ifdef PH_S2L_EXTRA_SALU  // sensitivity probe: PH_S2L_EXTRA_SALU x 8 scalar adds (or vector adds with PH_S2L_EXTRA_VALU) per pass
+        {
+          int dummy_s = q;
+#pragma unroll
+          for (int e = 0; e < PH_S2L_EXTRA_SALU; ++e)
+            asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 5\n\ts_add_u32 %0, %0, 7\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 5\n\ts_add_u32 %0, %0, 7" : "+s"(dummy_s) : : "scc");
+          if (dummy_s == 0x7fffff01) qc[7] = dummy_s;
+        }
+#endif
+#ifdef PH_S2L_EXTRA_VALU
+        {
+          int dummy_v = pair_lane();
+#pragma unroll
+          for (int e = 0; e < PH_S2L_EXTRA_VALU; ++e)
+            asm volatile("v_add_u32 %0, %0, %0\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %0, %0, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, %0, %0\n\tv_add_u32 %0, 5, %0\n\tv_add_u32 %0, %0, %0\n\tv_add_u32 %0, 7, %0" : "+v"(dummy_v));
+          if (dummy_v == 0x7fffff01) qc[7] = dummy_v;
+        }
+#endif
 #ifdef PH_S2L_TIMERS
         if (pair_lane() == 0) atomicAdd(&qc[5], 1);  // passes executed
 #endif

@@ -2,7 +2,8 @@
 // (1024 workgroups of 512 threads, 8 waves per SIMD, two rounds over the chip) through a loop of independent
 // instructions of one kind and reports cycles per instruction per SIMD (VALU) or per CU (SALU) from the hipEvent
 // time and the in-kernel clock (s_memtime / s_memrealtime).  The mixes at the end are the fold's group:
-// ds_read_b64 + v_pk_add_f32 (+ address adds + scalar loop code).
+// ds_read_b64 + v_pk_add_f32 (+ address adds + scalar loop code).  (s_add_u32 writes SCC: without the "scc" clobber the
+// loop around the scalar modes never ends.)
 //   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -43,10 +44,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                          "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf"
                          : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));)
     } else if (MODE == 5) {  // s_add_u32 (64 per iteration)
-      REP16(asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 5\n\ts_add_u32 %0, %0, 7" : "+s"(sc));)
+      REP16(asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 5\n\ts_add_u32 %0, %0, 7" : "+s"(sc) : : "scc");)
     } else if (MODE == 6) {  // 2 v_pk_add_f32 + 2 s_add_u32 interleaved (x16): do the scalar ones ride along?
       REP16(asm volatile("v_pk_add_f32 %0, %0, %3\n\ts_add_u32 %2, %2, 1\n\tv_pk_add_f32 %1, %1, %3\n\ts_add_u32 %2, %2, 3"
-                         : "+v"(a0), "+v"(a1), "+s"(sc) : "v"(inc));)
+                         : "+v"(a0), "+v"(a1), "+s"(sc) : "v"(inc) : "scc");)
     } else if (MODE == 7) {  // the fold's group: 16 ds_read_b64, wait, 16 v_pk_add_f32
       REP16(asm volatile("ds_read_b64 %0, %1" : "=v"(l0) : "v"(addr)); a0 += l0;)
     } else if (MODE == 8) {  // group of 4 loads issued together, one wait, 4 pk adds, one address add, scalar loop code (x4)
