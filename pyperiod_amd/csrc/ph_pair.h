@@ -60,6 +60,23 @@ __device__ __forceinline__ int pair_lane() {
   return l;
 }
 
+typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
+
+// ds_add_rtn_u32 by the calling lane: `atomicAdd` on LDS goes through the compiler's atomic optimiser, which wraps the one
+// active lane's add into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane, v_add)
+__device__ __forceinline__ int lds_ticket(int* counter) {
+  int old;
+  const __attribute__((address_space(3))) int* p = (const __attribute__((address_space(3))) int*)counter;
+  const int one = 1;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(p), "v"(one) : "memory");
+  return old;  // NOT waited for: the compiler does not count the asm's LDS operation -- read it with lds_ticket_value
+}
+// the ticket of lane 0 as a wave-uniform value (claim early, look at it after the pass: the wait is free by then)
+__device__ __forceinline__ int lds_ticket_value(int t) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t));
+  return __builtin_amdgcn_readfirstlane(t);
+}
+
 // ---------------------------------------------------------------- few-row single passes (R <= 6)
 template <int NR, int C, bool MASK, bool MX>
 __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int lane, f2& part) {
@@ -103,11 +120,31 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
                                                const float (&wgt)[7], f2 (&part)[3]) {
   static_assert(U % M == 0, "a row block must cover whole class cycles");
   f2 a[M][C];
-#pragma unroll
-  for (int u = 0; u < M; ++u)
-#pragma unroll
-    for (int c = 0; c < C; ++c) a[u][c] = f2_zero();
   int r = 0;
+  if (nrows >= U) {  // the first row block initialises the class sums (no zeroing, no adds)
+    f2 v[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        a[u][c] = v[u][c];
+#pragma unroll
+        for (int w = u + M; w < U; w += M) a[u][c] += v[w][c];
+      }
+    ptr += U * p;
+    r = U;
+  } else {
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u][c] = f2_zero();
+  }
   for (; r + U <= nrows; r += U) {
     f2 v[U][C];
 #pragma unroll
@@ -139,10 +176,10 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    if (MASK && c == C - 1) {  // a masked group holds exactly the chunks that are left: only the last one is cut
-#pragma unroll
-      for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : f2_zero();
-    }
+    // a masked group holds exactly the chunks that are left: only the last one is cut -- one class by zeroing its sum,
+    // several classes by running their squares under the lane mask (two scalar instructions instead of 2 M selects)
+    if (MASK && c == C - 1 && M == 1) a[0][c] = (64 * c + lane < nvalid) ? a[0][c] : f2_zero();
+    if (MASK && c == C - 1 && M > 1 && !(64 * c + lane < nvalid)) continue;
     if (M == 1) {
       part[0] = f2_acc<MX>(part[0], a[0][c]);
     } else if (MX) {  // max |S| of p, 2p and (M == 4) 4p from the class sums; no count weights
@@ -314,6 +351,78 @@ __device__ __forceinline__ f2 pair_pass_single(const f2* __restrict__ xs, int p,
   }
   if (MX) return f2_max(sa, sb);
   return f2_fma(sa, f2_make(g.w_full, g.w_full), sb * g.w_short);
+}
+
+// ---------------------------------------------------------------- multi-class pass, straight-line segments
+// Same sums as pair_pass_seg<M> (M = 2, 4), without its segment loop: the weights of a segment are compile-time
+// indexed, the tail of a segment is chosen by two compares, and no flag survives a branch.
+template <int M, bool MX>
+__device__ __forceinline__ void pair_multi_segment(pair_ptr base, int p, int len, int nrows, int lane,
+                                                   const float (&wgt)[7], f2 (&part)[3]) {
+  constexpr int CM = (M == 4) ? 2 : 4;
+  const int whole = len >> 6;
+  int c = 0;
+  for (; c + CM <= whole; c += CM) pair_seg_group<M, M, CM, false, MX>(base + 64 * c, p, nrows, 64 * CM, lane, wgt, part);
+  const int left = len - 64 * c;  // < 64 CM columns
+  const pair_ptr at = base + 64 * c;
+  if (CM == 4 && left > 128) {
+    if (left > 192) pair_seg_group<M, M, (CM == 4 ? 4 : 1), true, MX>(at, p, nrows, left, lane, wgt, part);
+    else pair_seg_group<M, M, (CM == 4 ? 3 : 1), true, MX>(at, p, nrows, left, lane, wgt, part);
+  } else if (left > 64) {
+    pair_seg_group<M, M, 2, true, MX>(at, p, nrows, left, lane, wgt, part);
+  } else if (left > 0) {
+    pair_seg_group<M, M, 1, true, MX>(at, p, nrows, left, lane, wgt, part);
+  }
+}
+
+// (x < y) ? a : b of wave-uniform values on the scalar unit (the compiler's version of a float select under a scalar
+// condition is two v_mov and a v_cndmask)
+__device__ __forceinline__ float scalar_select_lt(int x, int y, float a, float b) {
+  float r;
+  asm("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(x), "s"(y), "s"(a), "s"(b) : "scc");
+  return r;
+}
+
+template <int M, bool MX = false>
+__device__ __forceinline__ void pair_pass_multi(const f2* __restrict__ xs, int p, const PGeomF* __restrict__ geom,
+                                                f2 (&total)[3]) {
+  static_assert(M == 2 || M == 4, "two or four classes");
+  const PGeomF g1 = geom[p], g2 = geom[2 * p], g4 = geom[(M == 4 ? 4 : 2) * p];
+  const int lane = pair_lane();
+  const int cut = g1.nfull, rest = p - cut;
+  const pair_ptr a = (pair_ptr)xs + lane;
+  // class u of period 2p / 4p at column j is the residue u p + j: a whole segment lies on one side of nfull(2p), nfull(4p)
+  float wa[7], wb[7];
+  wa[0] = g1.w_full;
+  wb[0] = g1.w_short;
+  wa[1] = g2.w_full;  // residue 0 is never short
+  wa[3] = g4.w_full;
+  if (!MX) {
+    wa[2] = scalar_select_lt(p, g2.nfull, g2.w_full, g2.w_short);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wb[1 + u] = scalar_select_lt(cut + u * p, g2.nfull, g2.w_full, g2.w_short);
+#pragma unroll
+    for (int u = 1; u < 4; ++u) wa[3 + u] = M == 4 ? scalar_select_lt(u * p, g4.nfull, g4.w_full, g4.w_short) : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wb[3 + u] = M == 4 ? scalar_select_lt(cut + u * p, g4.nfull, g4.w_full, g4.w_short) : 0.0f;
+  }
+  if (M == 4) {  // the weights are applied per chunk, straight into the totals
+    total[0] = total[1] = total[2] = f2_zero();
+    pair_multi_segment<M, MX>(a, p, cut, g1.rows, lane, wa, total);
+    if (rest > 0) pair_multi_segment<M, MX>(a + cut, p, rest, g1.rows - 1, lane, wb, total);
+    return;
+  }
+  f2 sa[3] = {f2_zero(), f2_zero(), f2_zero()}, sb[3] = {f2_zero(), f2_zero(), f2_zero()};
+  pair_multi_segment<M, MX>(a, p, cut, g1.rows, lane, wa, sa);
+  if (rest > 0) pair_multi_segment<M, MX>(a + cut, p, rest, g1.rows - 1, lane, wb, sb);
+  if (MX) {
+    total[0] = f2_max(sa[0], sb[0]);
+    total[1] = f2_max(sa[1], sb[1]);
+  } else {
+    total[0] = f2_fma(sa[0], f2_make(wa[0], wa[0]), sb[0] * wb[0]);
+    total[1] = f2_fma(sa[1], f2_make(wa[1], wa[1]), f2_fma(sa[2], f2_make(wa[2], wa[2]), f2_fma(sb[1], f2_make(wb[1], wb[1]), sb[2] * wb[2])));
+  }
+  total[2] = f2_zero();
 }
 
 // p < 64: row-split path of wave_fold_small / wave_partial_small for pairs.
@@ -528,15 +637,9 @@ __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N
   // `queue` (an LDS counter the caller has set to `stride`, the number of wavefronts): the passes are taken in plan
   // order by whichever wavefront is free -- the passes differ in cost and the sweep ends at a barrier.
   for (int i = i_first; i < i_end;) {
-    int nxt = i + stride;
-    if (queue) {
-      int t = 0;
-      if (pair_lane() == 0) t = atomicAdd(queue, 1);
-      nxt = __builtin_amdgcn_readfirstlane(t);
-    }
-    const int i_now = i;
-    i = nxt;
-    const int p = plan[i_now].p, m = plan[i_now].m;
+    int ticket = 0;
+    if (queue && pair_lane() == 0) ticket = lds_ticket(queue);  // the next pass: claimed now, looked at after this one
+    const int p = plan[i].p, m = plan[i].m;
     if (m >= 8) {
       pair_chain_small<MX>(xs, N, p, m - 8, geom, consume, consume2);
     } else if (m == 0) {
@@ -545,14 +648,15 @@ __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N
       consume(red(pair_pass_single<MX>(xs, p, geom[p])), p);
     } else if (m == 2) {
       f2 part[3];
-      pair_pass_seg<2, MX>(xs, p, geom, part);
+      pair_pass_multi<2, MX>(xs, p, geom, part);
       consume2(pair_wave_red2<MX>(part[0], part[1]), p, 2 * p);
     } else {
       f2 part[3];
-      pair_pass_seg<4, MX>(xs, p, geom, part);
+      pair_pass_multi<4, MX>(xs, p, geom, part);
       consume2(pair_wave_red2<MX>(part[0], part[1]), p, 2 * p);
       consume(red(part[2]), 4 * p);
     }
+    i = queue ? lds_ticket_value(ticket) : i + stride;
   }
 }
 

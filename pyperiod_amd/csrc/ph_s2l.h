@@ -112,17 +112,7 @@ constexpr int kStampCap = 65536;
 __device__ long long g_ph_stamps[4 * kStampCap];  // diagnostic build only (tools/s2l_clocks.py)
 #endif
 constexpr int kS2LInf = 0x7fffffff;
-typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
 
-// ds_add_rtn_u32 by the calling lane: `atomicAdd` on LDS goes through the compiler's atomic optimiser, which wraps the one
-// active lane's add into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane, v_add)
-__device__ __forceinline__ int lds_ticket(int* counter) {
-  int old;
-  const __attribute__((address_space(3))) int* p = (const __attribute__((address_space(3))) int*)counter;
-  const int one = 1;
-  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(p), "v"(one) : "memory");
-  return old;  // (the caller's readfirstlane waits for lgkmcnt)
-}
 enum { S2L_TICK = 0, S2L_LIMIT, S2L_STOP0, S2L_STOP1, S2L_SKIP, S2L_QWORDS = 8 };
 
 // LDS of one workgroup (host and device agree through this one function)
@@ -300,7 +290,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           if (f1) atomicMin(&qc[S2L_STOP1], q);
           atomicMin(&qc[S2L_LIMIT], q);
         }
-        q = __builtin_amdgcn_readfirstlane(nxt);
+        q = lds_ticket_value(nxt);
 #ifdef PH_S2L_EXTRA_SALU  // sensitivity probe: PH_S2L_EXTRA_SALU x 8 scalar adds (or vector adds with PH_S2L_EXTRA_VALU) per pass
         {
           int dummy_s = q;

@@ -1,10 +1,10 @@
 // Test bed for the single-period screen pass of the window-pair kernels (ph_pair.h): every wavefront of a workgroup
 // walks the periods q_lo + wave, q_lo + wave + 8, ... < q_hi over one LDS window pair, as the screens of
 // k_small_to_large_pair / k_mbest_step1_pair do, at their occupancy (4 workgroups of 8 wavefronts per CU).  Variant 0 is
-// pair_pass_seg<1>, the others are candidates; the values of all variants are compared per period.  Time from
+// pair_pass_seg<1>, 1 is pair_pass_single, 2 / 3 are the two- and four-class passes (period q, 2q, 4q from one fold); the values of all variants are compared per period.  Time from
 // hipEvents; instruction counts per pass with
 //   rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES -- ./pair_pass_bench <variant>
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pyperiod_amd/csrc pair_pass_bench.hip -o pair_pass_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I../../pyperiod_amd/csrc pair_pass_bench.hip -o pair_pass_bench
 #include "ph_pair.h"
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     xs[i] = f2_make(v, 0.5f * v + 0.125f);
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform, as the pass queues of the kernels deliver it
   for (int r = 0; r < reps; ++r) {
     for (int q = q_lo + wave; q < q_hi; q += 8) {
       f2 tot;
@@ -31,8 +31,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         f2 part[3];
         pair_pass_seg<1, false>(xs, q, geom, part);
         tot = pair_wave_sum(part[0]);
-      } else {
+      } else if (V == 1) {
         tot = pair_wave_sum(pair_pass_single<false>(xs, q, geom[q]));
+      } else if (V == 2 || V == 3) {  // the multi-class passes as k_mbest_step1_pair runs them (q, 2q[, 4q] from one fold)
+        f2 part[3];
+        pair_pass_seg<V == 2 ? 2 : 4, false>(xs, q, geom, part);
+        tot = pair_wave_red2<false>(part[0], part[1]);
+        if (V == 3) tot += pair_wave_sum(part[2]);
+      } else {  // 4 / 5: pair_pass_multi, the straight-line version of 2 / 3
+        f2 part[3];
+        pair_pass_multi<V == 4 ? 2 : 4, false>(xs, q, geom, part);
+        tot = pair_wave_red2<false>(part[0], part[1]);
+        if (V == 5) tot += pair_wave_sum(part[2]);
       }
       if (blockIdx.x == 0 && r == 0 && pair_lane() == 0) {
         out[2 * q] = tot.x;
@@ -63,13 +73,13 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const size_t lds = (size_t)(N + 64) * sizeof(f2);
-  for (int v = 0; v < 2; ++v) {
-    if (only >= 0 && v != only) continue;
-    void (*fn)(const PGeomF*, int, int, int, int, float*) = v == 0 ? k<0> : k<1>;
+  for (int v = 0; v < 6; ++v) {
+    if (only >= 0 ? v != only && v != only + 2 : v >= 2) continue;
+    void (*fn)(const PGeomF*, int, int, int, int, float*) = v == 0 ? k<0> : v == 1 ? k<1> : v == 2 ? k<2> : v == 3 ? k<3> : v == 4 ? k<4> : k<5>;
     float best = 1e9;
     for (int r = 0; r < 3; ++r) {
       hipEventRecord(e0);
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, 0, dg, N, q_lo, q_hi, reps, out[v]);
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, 0, dg, N, q_lo, q_hi, reps, out[(v == 1 || v >= 4) ? 1 : 0]);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
@@ -81,7 +91,7 @@ int main(int argc, char** argv) {
     printf("variant %d: %.3f ms for %.0f passes (q in [%d, %d)): %.1f ns per pass per CU\n", v, best, passes, q_lo, q_hi,
            best * 1e6 / (passes / 256.0));
   }
-  if (only < 0) {
+  if (only < 0 || only == 2 || only == 3) {
     std::vector<float> h0(2 * (N + 1)), h1(2 * (N + 1));
     hipMemcpy(h0.data(), out[0], h0.size() * 4, hipMemcpyDeviceToHost);
     hipMemcpy(h1.data(), out[1], h1.size() * 4, hipMemcpyDeviceToHost);
