@@ -36,6 +36,24 @@ struct Tables {
   const int* fac_q;
 };
 
+// ---------------------------------------------------------------- LDS tickets
+typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
+
+// ds_add_rtn_u32 by the calling lane: `atomicAdd` on LDS goes through the compiler's atomic optimiser, which wraps the one
+// active lane's add into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane, v_add)
+__device__ __forceinline__ int lds_ticket(int* counter) {
+  int old;
+  const __attribute__((address_space(3))) int* p = (const __attribute__((address_space(3))) int*)counter;
+  const int one = 1;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(p), "v"(one) : "memory");
+  return old;  // NOT waited for: the compiler does not count the asm's LDS operation -- read it with lds_ticket_value
+}
+// the ticket of lane 0 as a wave-uniform value (claim early, look at it after the pass: the wait is free by then)
+__device__ __forceinline__ int lds_ticket_value(int t) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t));
+  return __builtin_amdgcn_readfirstlane(t);
+}
+
 // ---------------------------------------------------------------- wavefront / block reductions
 // Cross-lane moves for doubles on gfx950 without ds_bpermute (which costs LDS cycles and a per-lane address
 // register per step -- registers the 64-VGPR kernels spill): DPP moves data inside a row of 16 lanes,
@@ -474,17 +492,12 @@ __device__ __forceinline__ double wave_partial_small(const T* __restrict__ xs, i
   return (lane < p) ? tot * tot * w : 0.0;
 }
 
-template <typename T, int M, bool MAXABS, bool LDS>
-__device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
-                                              int lane, double (&part)[3]);
+template <typename T, bool MAXABS, bool LDS>
+__device__ __forceinline__ double wave_pass_single(const T* __restrict__ xs, int p, const PGeom g, int lane);
 
 template <typename T, bool MAXABS, bool LDS = true>
 __device__ __forceinline__ double wave_partial(const T* __restrict__ xs, int N, int p, const PGeom& g, int lane) {
-  if (p >= 64) {
-    double part[3];
-    wave_pass_seg<T, 1, MAXABS, LDS>(xs, p, &g - p, lane, part);  // &g == geom + p
-    return part[0];
-  }
+  if (p >= 64) return wave_pass_single<T, MAXABS, LDS>(xs, p, g, lane);
   return MAXABS ? wave_partial_small_maxabs(xs, p, g, lane) : wave_partial_small(xs, N, p, g, lane);
 }
 
@@ -645,11 +658,31 @@ __device__ __forceinline__ void seg_group(typename Win<T, LDS>::ptr ptr, int p, 
                                           const double (&wgt)[7], double (&part)[3]) {
   static_assert(U % M == 0, "a row block must cover whole class cycles");
   double a[M][C];
-#pragma unroll
-  for (int u = 0; u < M; ++u)
-#pragma unroll
-    for (int c = 0; c < C; ++c) a[u][c] = 0.0;
   int r = 0;
+  if (nrows >= U) {  // the first row block initialises the class sums (no zeroing, no adds; same row order)
+    T v[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[u][c] = ptr[u * p + 64 * c];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        a[u][c] = (double)v[u][c];
+#pragma unroll
+        for (int w = u + M; w < U; w += M) a[u][c] += (double)v[w][c];
+      }
+    ptr += U * p;
+    r = U;
+  } else {
+#pragma unroll
+    for (int u = 0; u < M; ++u)
+#pragma unroll
+      for (int c = 0; c < C; ++c) a[u][c] = 0.0;
+  }
   for (; r + U <= nrows; r += U) {
     T v[U][C];
 #pragma unroll
@@ -683,10 +716,10 @@ __device__ __forceinline__ void seg_group(typename Win<T, LDS>::ptr ptr, int p, 
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    if (MASK && c == C - 1) {  // last group of the segment, holding exactly the chunks that are left: lanes past the end of the LAST one hold garbage
-#pragma unroll
-      for (int u = 0; u < M; ++u) a[u][c] = (64 * c + lane < nvalid) ? a[u][c] : 0.0;
-    }
+    // last group of the segment, holding exactly the chunks that are left: lanes past the end of the LAST one hold
+    // garbage -- one class: its sum is zeroed; several classes: their squares run under the lane mask
+    if (MASK && c == C - 1 && M == 1) a[0][c] = (64 * c + lane < nvalid) ? a[0][c] : 0.0;
+    if (MASK && c == C - 1 && M > 1 && !(64 * c + lane < nvalid)) continue;
     if (M == 1) {  // M <= 2: plain sums of squares per class, weighted once per segment
       const double t = a[0][c];
       part[0] = MAXABS ? fmax(part[0], fabs(t)) : fma(t, t, part[0]);
@@ -845,6 +878,133 @@ __device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, c
   }
 }
 
+// ---------------------------------------------------------------- passes with one dispatch (round 4)
+// wave_pass_seg walks its two segments in a loop: per segment a dozen scalar selects, the compare chain of the row
+// switch and the flags of its fall-through -- on a CU whose ONE scalar unit serves 32 wavefronts
+// (tools/micro/valu_rate.hip: 1.05 cycles per s_add_u32 per CU).  The versions below dispatch once per pass and run both
+// segments as straight-line code with compile-time indexed weights; sums and their order are those of wave_pass_seg.
+__device__ __forceinline__ double scalar_select_lt(int x, int y, double a, double b) {  // (x < y) ? a : b, wave-uniform
+  double r;
+  asm("s_cmp_lt_i32 %1, %2\n\ts_cselect_b64 %0, %3, %4" : "=s"(r) : "s"(x), "s"(y), "s"(a), "s"(b) : "scc");
+  return r;
+}
+
+template <typename T, int NR, bool LDS>
+__device__ __forceinline__ double wave_single_rows(typename Win<T, LDS>::ptr base, int p, int len, int lane) {
+  constexpr int CG = NR <= 4 ? 4 : 2;
+  double part = 0.0;
+  const int whole = len >> 6;
+  int c = 0;
+  for (; c + CG <= whole; c += CG) rows_group<T, NR, CG, false, LDS>(base + 64 * c, p, 0, lane, part);
+  for (; c < whole; ++c) {
+    asm volatile("" ::: "memory");
+    rows_group<T, NR, 1, false, LDS>(base + 64 * c, p, 0, lane, part);
+  }
+  const int rem = len & 63;
+  if (rem) {
+    asm volatile("" ::: "memory");
+    rows_group<T, NR, 1, true, LDS>(base + 64 * whole, p, rem, lane, part);
+  }
+  return part;
+}
+
+// one segment of an M-class pass: columns [0, len) from `base` (lane included), nrows samples each
+template <typename T, int M, int U, bool MAXABS, bool LDS>
+__device__ __forceinline__ void wave_multi_segment(typename Win<T, LDS>::ptr base, int p, int len, int nrows, int lane,
+                                                   const double (&wgt)[7], double (&part)[3]) {
+  constexpr int CM = (M == 4) ? 2 : 4;
+  const int whole = len >> 6;
+  int c = 0;
+  for (; c + CM <= whole; c += CM) seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c, p, nrows, 64 * CM, lane, wgt, part);
+  const int left = len - 64 * c;  // < 64 CM columns
+  const typename Win<T, LDS>::ptr at = base + 64 * c;
+  if (CM == 4 && left > 128) {
+    if (left > 192) seg_group<T, M, U, (CM == 4 ? 4 : 1), MAXABS, true, LDS>(at, p, nrows, left, lane, wgt, part);
+    else seg_group<T, M, U, (CM == 4 ? 3 : 1), MAXABS, true, LDS>(at, p, nrows, left, lane, wgt, part);
+  } else if (left > 64) {
+    seg_group<T, M, U, 2, MAXABS, true, LDS>(at, p, nrows, left, lane, wgt, part);
+  } else if (left > 0) {
+    seg_group<T, M, U, 1, MAXABS, true, LDS>(at, p, nrows, left, lane, wgt, part);
+  }
+}
+
+// Per-lane partial of ||P_p x||^2 (MAXABS: of max_s |S_p[s]|, row-order sums), p >= 64
+template <typename T, bool MAXABS, bool LDS>
+__device__ __forceinline__ double wave_pass_single(const T* __restrict__ xs, int p, const PGeom g, int lane) {
+  typedef typename Win<T, LDS>::ptr lds_ptr;
+  const lds_ptr a = Win<T, LDS>::cast(xs) + lane, b = a + g.nfull;
+  const int cut = g.nfull, rest = p - cut;
+  double sa, sb;
+  bool done = false;
+  if (!MAXABS) {  // few rows: compile-time row count (norm passes only: the max|S| kernels spill)
+    done = true;
+    switch (g.rows) {
+      case 2: sa = wave_single_rows<T, 2, LDS>(a, p, cut, lane); sb = wave_single_rows<T, 1, LDS>(b, p, rest, lane); break;
+      case 3: sa = wave_single_rows<T, 3, LDS>(a, p, cut, lane); sb = wave_single_rows<T, 2, LDS>(b, p, rest, lane); break;
+      case 4: sa = wave_single_rows<T, 4, LDS>(a, p, cut, lane); sb = wave_single_rows<T, 3, LDS>(b, p, rest, lane); break;
+      case 5: sa = wave_single_rows<T, 5, LDS>(a, p, cut, lane); sb = wave_single_rows<T, 4, LDS>(b, p, rest, lane); break;
+      case 6: sa = wave_single_rows<T, 6, LDS>(a, p, cut, lane); sb = wave_single_rows<T, 5, LDS>(b, p, rest, lane); break;
+      default: done = false; break;
+    }
+  }
+  if (!done) {
+#ifndef PH_U1
+#define PH_U1 2  // rows per load block of single-period passes (tuning knob)
+#endif
+    const double wgt[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double pa[3] = {0.0, 0.0, 0.0}, pb[3] = {0.0, 0.0, 0.0};
+    wave_multi_segment<T, 1, PH_U1, MAXABS, LDS>(a, p, cut, g.rows, lane, wgt, pa);
+    if (rest > 0) wave_multi_segment<T, 1, PH_U1, MAXABS, LDS>(b, p, rest, g.rows - 1, lane, wgt, pb);
+    sa = pa[0];
+    sb = pb[0];
+  }
+  return MAXABS ? fmax(sa, sb) : fma(sb, g.w_short, sa * g.w_full);  // (the order of wave_pass_seg: bit-identical values)
+}
+
+// Per-lane partials for q = p, 2p (and 4p, M == 4), base period p >= 64: total[0], total[1], total[2]
+template <typename T, int M, bool MAXABS, bool LDS>
+__device__ __forceinline__ void wave_pass_multi(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom, int lane,
+                                                double (&total)[3]) {
+  static_assert(M == 2 || M == 4, "two or four classes");
+  typedef typename Win<T, LDS>::ptr lds_ptr;
+  const PGeom g1 = geom[p], g2 = geom[2 * p], g4 = geom[(M == 4 ? 4 : 2) * p];
+  const int cut = g1.nfull, rest = p - cut;
+  const lds_ptr a = Win<T, LDS>::cast(xs) + lane;
+  double wa[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, wb[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (!MAXABS) {
+    wa[0] = g1.w_full;
+    wb[0] = g1.w_short;
+    wa[1] = g2.w_full;  // residue 0 is never short
+    wa[3] = g4.w_full;
+    wa[2] = scalar_select_lt(p, g2.nfull, g2.w_full, g2.w_short);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wb[1 + u] = scalar_select_lt(cut + u * p, g2.nfull, g2.w_full, g2.w_short);
+    if (M == 4) {
+#pragma unroll
+      for (int u = 1; u < 4; ++u) wa[3 + u] = scalar_select_lt(u * p, g4.nfull, g4.w_full, g4.w_short);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wb[3 + u] = scalar_select_lt(cut + u * p, g4.nfull, g4.w_full, g4.w_short);
+    }
+  }
+  if (M == 4) {  // weights (or maxima) applied per chunk, straight into the totals
+    total[0] = total[1] = total[2] = 0.0;
+    wave_multi_segment<T, M, M, MAXABS, LDS>(a, p, cut, g1.rows, lane, wa, total);
+    if (rest > 0) wave_multi_segment<T, M, M, MAXABS, LDS>(a + cut, p, rest, g1.rows - 1, lane, wb, total);
+    return;
+  }
+  double sa[3] = {0.0, 0.0, 0.0}, sb[3] = {0.0, 0.0, 0.0};
+  wave_multi_segment<T, M, M, MAXABS, LDS>(a, p, cut, g1.rows, lane, wa, sa);
+  if (rest > 0) wave_multi_segment<T, M, M, MAXABS, LDS>(a + cut, p, rest, g1.rows - 1, lane, wb, sb);
+  if (MAXABS) {
+    total[0] = fmax(sa[0], sb[0]);
+    total[1] = fmax(sa[1], sb[1]);
+  } else {
+    total[0] = fma(sb[0], wb[0], sa[0] * wa[0]);  // (the order of wave_pass_seg: bit-identical values)
+    total[1] = fma(sb[1], wb[1], fma(sb[2], wb[2], fma(sa[1], wa[1], sa[2] * wa[2])));
+  }
+  total[2] = 0.0;
+}
+
 // The online 8-period butterfly of wave_sweep as a state machine, for producers that deliver
 // one to three periods at a time.  `k` is wave-uniform.
 template <bool MAXABS = false>
@@ -916,31 +1076,26 @@ __device__ __forceinline__ void wave_sweep_plan(const T* __restrict__ xs, int N,
   Butterfly8<MAXABS> bf;
   bf.reset();
   for (int i = i_first; i < i_end;) {
-    int nxt = i + stride;
-    if (queue) {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(queue, 1);
-      nxt = __builtin_amdgcn_readfirstlane(t);
-    }
-    const int i_now = i;
-    i = nxt;
-    const int p = plan[i_now].p, m = plan[i_now].m;
+    int ticket = 0;
+    if (queue && lane == 0) ticket = lds_ticket(queue);  // the next pass: claimed now, looked at after this one
+    const int p = plan[i].p, m = plan[i].m;
     if (m >= 8) {
       wave_chain_small<T, MAXABS>(xs, N, p, m - 8, geom, lane, bf, consume);
     } else if (m <= 1) {
       bf.push(wave_partial<T, MAXABS, LDS>(xs, N, p, geom[p], lane), p, lane, consume);
     } else if (m == 2) {
       double part[3];
-      wave_pass_seg<T, 2, MAXABS, LDS>(xs, p, geom, lane, part);
+      wave_pass_multi<T, 2, MAXABS, LDS>(xs, p, geom, lane, part);
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
     } else {
       double part[3];
-      wave_pass_seg<T, 4, MAXABS, LDS>(xs, p, geom, lane, part);
+      wave_pass_multi<T, 4, MAXABS, LDS>(xs, p, geom, lane, part);
       bf.push(part[0], p, lane, consume);
       bf.push(part[1], 2 * p, lane, consume);
       bf.push(part[2], 4 * p, lane, consume);
     }
+    i = queue ? lds_ticket_value(ticket) : i + stride;
   }
   bf.flush(lane, consume);
 }

@@ -60,23 +60,6 @@ __device__ __forceinline__ int pair_lane() {
   return l;
 }
 
-typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
-
-// ds_add_rtn_u32 by the calling lane: `atomicAdd` on LDS goes through the compiler's atomic optimiser, which wraps the one
-// active lane's add into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane, v_add)
-__device__ __forceinline__ int lds_ticket(int* counter) {
-  int old;
-  const __attribute__((address_space(3))) int* p = (const __attribute__((address_space(3))) int*)counter;
-  const int one = 1;
-  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(p), "v"(one) : "memory");
-  return old;  // NOT waited for: the compiler does not count the asm's LDS operation -- read it with lds_ticket_value
-}
-// the ticket of lane 0 as a wave-uniform value (claim early, look at it after the pass: the wait is free by then)
-__device__ __forceinline__ int lds_ticket_value(int t) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t));
-  return __builtin_amdgcn_readfirstlane(t);
-}
-
 // ---------------------------------------------------------------- few-row single passes (R <= 6)
 template <int NR, int C, bool MASK, bool MX>
 __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int lane, f2& part) {
