@@ -6,7 +6,7 @@
 //   * thread-per-residue, rows accumulated in order r = 0..R-1: bit-identical to the
 //     reference's np.sum(cp, 0) (Periods.py:194).  Used wherever a projection is
 //     materialised (bases, residual updates).
-//   * wave-per-period passes (seg_group / wave_pass_seg): one 64-lane wavefront owns a base
+//   * wave-per-period passes (seg_group / wave_pass_single / wave_pass_multi): one 64-lane wavefront owns a base
 //     period p, lanes own residues, consecutive lanes read consecutive LDS words
 //     (conflict-free ds_read_b64).  The base residues are split at N mod p, which makes the row
 //     count and every count weight wave-uniform; one pass can also yield the folds of 2p and
@@ -773,116 +773,14 @@ __device__ __forceinline__ void rows_group(typename Win<T, LDS>::ptr ptr, int p,
   }
 }
 
-template <typename T, int NR, bool LDS>
-__device__ __forceinline__ void rows_segment(typename Win<T, LDS>::ptr base, int p, int len, int lane, double& part) {
-  constexpr int CG = NR <= 4 ? 4 : 2;  // NR x CG loads (<= 16) in flight per wave
-  const int nchunks = (len + 63) >> 6;
-  const int whole = len >> 6;
-  int c0 = 0;
-  for (; c0 + CG <= whole; c0 += CG) rows_group<T, NR, CG, false, LDS>(base + 64 * c0, p, 64 * CG, lane, part);
-  for (; c0 + 1 < nchunks; c0 += 2) {
-    asm volatile("" ::: "memory");
-    rows_group<T, NR, 2, true, LDS>(base + 64 * c0, p, len - 64 * c0, lane, part);
-  }
-  if (c0 < nchunks) {
-    asm volatile("" ::: "memory");
-    rows_group<T, NR, 1, true, LDS>(base + 64 * c0, p, len - 64 * c0, lane, part);
-  }
-}
-
-// Per-lane partials of ||P_q x||^2 for q = p (M >= 1), 2p (M >= 2), 4p (M == 4) -- or of
-// max_s |S_p[s]| (MAXABS, M == 1, row-order sums) -- for a base period p >= 64.
-template <typename T, int M, bool MAXABS, bool LDS>
-__device__ __forceinline__ void wave_pass_seg(const T* __restrict__ xs, int p, const PGeom* __restrict__ geom,
-                                              int lane, double (&total)[3]) {
-  typedef typename Win<T, LDS>::ptr lds_ptr;
-#ifndef PH_U1
-#define PH_U1 2  // rows per load block of single-period passes (tuning knob)
-#endif
-  constexpr int U = (M == 1) ? PH_U1 : M;
-  constexpr int CM = (M == 4) ? 2 : 4;
-  const int rows = geom[p].rows, cut = geom[p].nfull;  // residues < cut own `rows` samples
-  int qn[3];
-  double qf[3], qs[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int q = (t == 0 || (t == 1 && M >= 2) || M == 4) ? (p << t) : p;
-    qn[t] = geom[q].nfull;
-    qf[t] = geom[q].w_full;
-    qs[t] = geom[q].w_short;
-    total[t] = 0.0;
-  }
-#pragma unroll 1
-  for (int seg = 0; seg < 2; ++seg) {
-    const int start = seg == 0 ? 0 : cut;
-    const int len = seg == 0 ? cut : p - cut;
-    if (len <= 0) continue;
-    const int nrows = seg == 0 ? rows : rows - 1;
-    double wgt[7];  // weight of residue class (t, u) in this segment: uniform, see above
-    wgt[0] = start < qn[0] ? qf[0] : qs[0];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) wgt[1 + u] = (start + u * p < qn[1]) ? qf[1] : qs[1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wgt[3 + u] = (start + u * p < qn[2]) ? qf[2] : qs[2];
-    const lds_ptr base = Win<T, LDS>::cast(xs) + start + lane;
-    const int nchunks = (len + 63) >> 6;
-    int c0 = 0;
-    const int whole = len >> 6;  // chunks whose 64 residues all belong to the segment
-    double sacc[3] = {0.0, 0.0, 0.0};
-    double(&part)[3] = (M <= 2) ? sacc : total;
-    bool done = false;
-    if (M == 1 && !MAXABS) {  // few rows: compile-time row count (norm passes only: the max|S| kernels spill)
-      done = true;
-      switch (nrows) {
-        case 1: rows_segment<T, 1, LDS>(base, p, len, lane, part[0]); break;
-        case 2: rows_segment<T, 2, LDS>(base, p, len, lane, part[0]); break;
-        case 3: rows_segment<T, 3, LDS>(base, p, len, lane, part[0]); break;
-        case 4: rows_segment<T, 4, LDS>(base, p, len, lane, part[0]); break;
-        case 5: rows_segment<T, 5, LDS>(base, p, len, lane, part[0]); break;
-        case 6: rows_segment<T, 6, LDS>(base, p, len, lane, part[0]); break;
-        default: done = false; break;
-      }
-    }
-    if (done) {
-      // whole segment folded by the unrolled-rows path
-    } else if (CM == 4) {
-      for (; c0 + CM <= whole; c0 += CM)
-        seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
-      switch (nchunks - c0) {
-        case 4: seg_group<T, M, U, 4, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 3: seg_group<T, M, U, 3, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 2: seg_group<T, M, U, 2, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: seg_group<T, M, U, 1, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        default: break;
-      }
-    } else {
-      for (; c0 + CM <= whole; c0 += CM)
-        seg_group<T, M, U, CM, MAXABS, false, LDS>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
-      switch (nchunks - c0) {
-        case 2: seg_group<T, M, U, 2, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: seg_group<T, M, U, 1, MAXABS, true, LDS>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        default: break;
-      }
-    }
-    if (M == 1) {
-      total[0] = MAXABS ? fmax(total[0], sacc[0]) : fma(sacc[0], wgt[0], total[0]);
-    } else if (M == 2) {
-      if (MAXABS) {
-        total[0] = fmax(total[0], sacc[0]);
-        total[1] = fmax(total[1], sacc[1]);
-      } else {
-        total[0] = fma(sacc[0], wgt[0], total[0]);
-        total[1] = fma(sacc[1], wgt[1], fma(sacc[2], wgt[2], total[1]));
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------- passes with one dispatch (round 4)
-// wave_pass_seg walks its two segments in a loop: per segment a dozen scalar selects, the compare chain of the row
-// switch and the flags of its fall-through -- on a CU whose ONE scalar unit serves 32 wavefronts
-// (tools/micro/valu_rate.hip: 1.05 cycles per s_add_u32 per CU).  The versions below dispatch once per pass and run both
-// segments as straight-line code with compile-time indexed weights; sums and their order are those of wave_pass_seg.
+// Per-lane partials of ||P_q x||^2 for q = p, 2p, 4p -- or of max_s |S_q[s]| (MAXABS) -- for a base period p >= 64.
+// Through round 3 a pass walked its two segments in a loop: per segment a dozen scalar selects, the compare chain of a
+// row-count switch and the flags of its fall-through -- on a CU whose ONE scalar unit serves 32 wavefronts
+// (tools/micro/valu_rate.hip: 1.05 cycles per s_add_u32 per CU; the sweeps kept it 70-90 % busy).  A pass now dispatches
+// once, on the row count of its base period, and runs both segments as straight-line code with compile-time indexed
+// weights (tools/micro/pair_pass_bench.hip measures the float-pair twins: -27 % scalar instructions per pass).  Sums and
+// their order are unchanged.
 __device__ __forceinline__ double scalar_select_lt(int x, int y, double a, double b) {  // (x < y) ? a : b, wave-uniform
   double r;
   asm("s_cmp_lt_i32 %1, %2\n\ts_cselect_b64 %0, %3, %4" : "=s"(r) : "s"(x), "s"(y), "s"(a), "s"(b) : "scc");
@@ -958,7 +856,7 @@ __device__ __forceinline__ double wave_pass_single(const T* __restrict__ xs, int
     sa = pa[0];
     sb = pb[0];
   }
-  return MAXABS ? fmax(sa, sb) : fma(sb, g.w_short, sa * g.w_full);  // (the order of wave_pass_seg: bit-identical values)
+  return MAXABS ? fmax(sa, sb) : fma(sb, g.w_short, sa * g.w_full);  // segment A's product is rounded first (rounds 1-3: same bits)
 }
 
 // Per-lane partials for q = p, 2p (and 4p, M == 4), base period p >= 64: total[0], total[1], total[2]
@@ -999,7 +897,7 @@ __device__ __forceinline__ void wave_pass_multi(const T* __restrict__ xs, int p,
     total[0] = fmax(sa[0], sb[0]);
     total[1] = fmax(sa[1], sb[1]);
   } else {
-    total[0] = fma(sb[0], wb[0], sa[0] * wa[0]);  // (the order of wave_pass_seg: bit-identical values)
+    total[0] = fma(sb[0], wb[0], sa[0] * wa[0]);  // segment A first, as in rounds 1-3: same bits
     total[1] = fma(sb[1], wb[1], fma(sb[2], wb[2], fma(sa[1], wa[1], sa[2] * wa[2])));
   }
   total[2] = 0.0;

@@ -80,23 +80,6 @@ __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid,
   }
 }
 
-template <int NR, bool MX>
-__device__ __forceinline__ void pair_rows_segment(pair_ptr base, int p, int len, int lane, f2& part) {
-  constexpr int CG = NR <= 4 ? 4 : 2;
-  const int nchunks = (len + 63) >> 6;
-  const int whole = len >> 6;
-  int c0 = 0;
-  for (; c0 + CG <= whole; c0 += CG) pair_rows_group<NR, CG, false, MX>(base + 64 * c0, p, 64 * CG, lane, part);
-  for (; c0 + 1 < nchunks; c0 += 2) {
-    asm volatile("" ::: "memory");
-    pair_rows_group<NR, 2, true, MX>(base + 64 * c0, p, len - 64 * c0, lane, part);
-  }
-  if (c0 < nchunks) {
-    asm volatile("" ::: "memory");
-    pair_rows_group<NR, 1, true, MX>(base + 64 * c0, p, len - 64 * c0, lane, part);
-  }
-}
-
 // ---------------------------------------------------------------- general segmented group (see seg_group)
 template <int M, int U, int C, bool MASK, bool MX>
 __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, int nvalid, int lane,
@@ -189,94 +172,11 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
   }
 }
 
-// Per-lane partials of sum_j S_q[j]^2 / cnt_q[j] of BOTH windows for q = p (M >= 1), 2p (M >= 2), 4p (M == 4),
-// base period p >= 64; same segment logic as wave_pass_seg.
-template <int M, bool MX = false>
-__device__ __forceinline__ void pair_pass_seg(const f2* __restrict__ xs, int p, const PGeomF* __restrict__ geom,
-                                              f2 (&total)[3]) {
-  constexpr int U = (M == 1) ? 2 : M;
-  constexpr int CM = (M == 4) ? 2 : 4;
-  const int rows = geom[p].rows, cut = geom[p].nfull;
-  int qn[3];
-  float qf[3], qs[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int q = (t == 0 || (t == 1 && M >= 2) || M == 4) ? (p << t) : p;
-    qn[t] = geom[q].nfull;
-    qf[t] = geom[q].w_full;
-    qs[t] = geom[q].w_short;
-    total[t] = f2_zero();
-  }
-#pragma unroll 1
-  for (int seg = 0; seg < 2; ++seg) {
-    const int start = seg == 0 ? 0 : cut;
-    const int len = seg == 0 ? cut : p - cut;
-    if (len <= 0) continue;
-    const int nrows = seg == 0 ? rows : rows - 1;
-    float wgt[7];
-    wgt[0] = start < qn[0] ? qf[0] : qs[0];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) wgt[1 + u] = (start + u * p < qn[1]) ? qf[1] : qs[1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wgt[3 + u] = (start + u * p < qn[2]) ? qf[2] : qs[2];
-    const int lane = pair_lane();
-    const pair_ptr base = (pair_ptr)xs + start + lane;
-    const int nchunks = (len + 63) >> 6;
-    int c0 = 0;
-    const int whole = len >> 6;
-    f2 sacc[3] = {f2_zero(), f2_zero(), f2_zero()};
-    f2(&part)[3] = (M <= 2) ? sacc : total;
-    bool done = false;
-    if (M == 1) {
-      done = true;
-      switch (nrows) {
-        case 1: pair_rows_segment<1, MX>(base, p, len, lane, part[0]); break;
-        case 2: pair_rows_segment<2, MX>(base, p, len, lane, part[0]); break;
-        case 3: pair_rows_segment<3, MX>(base, p, len, lane, part[0]); break;
-        case 4: pair_rows_segment<4, MX>(base, p, len, lane, part[0]); break;
-        case 5: pair_rows_segment<5, MX>(base, p, len, lane, part[0]); break;
-        case 6: pair_rows_segment<6, MX>(base, p, len, lane, part[0]); break;
-        default: done = false; break;
-      }
-    }
-    if (done) {
-    } else if (CM == 4) {
-      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false, MX>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
-      switch (nchunks - c0) {
-        case 4: pair_seg_group<M, U, 4, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 3: pair_seg_group<M, U, 3, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 2: pair_seg_group<M, U, 2, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: pair_seg_group<M, U, 1, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        default: break;
-      }
-    } else {
-      for (; c0 + CM <= whole; c0 += CM) pair_seg_group<M, U, CM, false, MX>(base + 64 * c0, p, nrows, 64 * CM, lane, wgt, part);
-      switch (nchunks - c0) {
-        case 2: pair_seg_group<M, U, 2, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        case 1: pair_seg_group<M, U, 1, true, MX>(base + 64 * c0, p, nrows, len - 64 * c0, lane, wgt, part); break;
-        default: break;
-      }
-    }
-    if (MX) {
-      if (M <= 2) {
-        total[0] = f2_max(total[0], sacc[0]);
-        total[1] = f2_max(total[1], sacc[1]);
-      }
-    } else if (M == 1) {
-      total[0] = f2_fma(sacc[0], f2_make(wgt[0], wgt[0]), total[0]);
-    } else if (M == 2) {
-      total[0] = f2_fma(sacc[0], f2_make(wgt[0], wgt[0]), total[0]);
-      total[1] = f2_fma(sacc[1], f2_make(wgt[1], wgt[1]), f2_fma(sacc[2], f2_make(wgt[2], wgt[2]), total[1]));
-    }
-  }
-}
-
 // ---------------------------------------------------------------- single-period pass with one dispatch
-// pair_pass_seg<1> walks its two segments in a loop and chooses the code of each by its row count: per segment a
-// dozen scalar selects, a compare chain and the flags of the fall-through, ~60 scalar instructions per pass before
-// the first load -- and one CU has ONE scalar unit for its 32 wavefronts (tools/micro/valu_rate.hip: 1.05 cycles per
-// s_add_u32 per CU), which the screens keep ~90 % busy.  Here the pass is dispatched once, on the row count of the
-// period, to straight-line code for both segments.
+// Per-lane partials of sum_j S_q[j]^2 / cnt_q[j] of BOTH windows, base period p >= 64; segment logic of seg_group.
+// The pass is dispatched once, on the row count of the period, to straight-line code for both segments (see "passes
+// with one dispatch" in ph_device.h: one CU has one scalar unit, and the screens kept it ~90 % busy; measured with
+// tools/micro/pair_pass_bench.hip: 129 -> 71 scalar instructions per few-row pass, 100 -> 85 ns per pass and CU).
 template <int NR, bool MX>
 __device__ __forceinline__ f2 pair_single_rows(pair_ptr base, int p, int len, int lane) {
   constexpr int CG = NR <= 4 ? 4 : 2;
@@ -337,8 +237,8 @@ __device__ __forceinline__ f2 pair_pass_single(const f2* __restrict__ xs, int p,
 }
 
 // ---------------------------------------------------------------- multi-class pass, straight-line segments
-// Same sums as pair_pass_seg<M> (M = 2, 4), without its segment loop: the weights of a segment are compile-time
-// indexed, the tail of a segment is chosen by two compares, and no flag survives a branch.
+// Period p, 2p (and 4p) from the class sums of one fold: the weights of a segment are compile-time indexed and chosen on
+// the scalar unit, the tail of a segment is picked by two compares, and no flag survives a branch.
 template <int M, bool MX>
 __device__ __forceinline__ void pair_multi_segment(pair_ptr base, int p, int len, int nrows, int lane,
                                                    const float (&wgt)[7], f2 (&part)[3]) {
