@@ -519,13 +519,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
     // ---- 1. screen of both windows (Periods.py:501-515 in float); values into the idle staging buffer
     f2* vals = reinterpret_cast<f2*>(stg);
     pair_sweep_plan(
-        pw, N, geomf, plan, wv, n_pass, nw, [&](f2 ss, int q) {
-          if (pair_lane() == 0) vals[q - p_lo] = ss;
-        },
-        [&](f2 ss, int q_lower, int q_upper) {
-          const int l = pair_lane();
-          if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = ss;
-        },
+        pw, N, geomf, plan, wv, n_pass, nw, [&](float z, int q) { pair_store1(vals, z, q, p_lo); },
+        [&](float z, int q_a, int q_b) { pair_store2(vals, z, q_a, q_b, p_lo); },
         PH_PAIR_QUEUE ? &ctl[14] : nullptr);
     __syncthreads();
     PH_PAIR_MARK(0)
@@ -1571,13 +1566,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PH_STEP1_W
       // ---- screen: largest square of a residue sum per period, both windows (Periods.py:324-331 in float)
       f2* vals = reinterpret_cast<f2*>(stg);
       pair_sweep_plan<true>(
-          pw, N, geomf, plan, wv, n_pass, nw, [&](f2 v, int q) {
-            if (pair_lane() == 0) vals[q - p_lo] = v;
-          },
-          [&](f2 v, int q_lower, int q_upper) {
-            const int l = pair_lane();
-            if ((l & 31) == 0) vals[(l < 32 ? q_lower : q_upper) - p_lo] = v;
-          },
+          pw, N, geomf, plan, wv, n_pass, nw, [&](float z, int q) { pair_store1(vals, z, q, p_lo); },
+          [&](float z, int q_a, int q_b) { pair_store2(vals, z, q_a, q_b, p_lo); },
           PH_PAIR_QUEUE ? &ctl[6] : nullptr);
       prio_short_phase();
       __syncthreads();

@@ -196,20 +196,23 @@ __device__ __forceinline__ f2 pair_single_rows(pair_ptr base, int p, int len, in
   return part;
 }
 
+#ifndef PH_PAIR_U1
+#define PH_PAIR_U1 2  // rows per load block of the many-row single passes
+#endif
 template <bool MX>
 __device__ __forceinline__ f2 pair_single_general(pair_ptr base, int p, int len, int nrows, int lane) {
   f2 part[3] = {f2_zero(), f2_zero(), f2_zero()};
   const float wgt[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   const int whole = len >> 6;
   int c = 0;
-  for (; c + 4 <= whole; c += 4) pair_seg_group<1, 2, 4, false, MX>(base + 64 * c, p, nrows, 256, lane, wgt, part);
+  for (; c + 4 <= whole; c += 4) pair_seg_group<1, PH_PAIR_U1, 4, false, MX>(base + 64 * c, p, nrows, 256, lane, wgt, part);
   const int left = len - 64 * c;  // < 256 columns
   if (left > 128) {
-    if (left > 192) pair_seg_group<1, 2, 4, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
-    else pair_seg_group<1, 2, 3, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    if (left > 192) pair_seg_group<1, PH_PAIR_U1, 4, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    else pair_seg_group<1, PH_PAIR_U1, 3, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
   } else if (left > 0) {
-    if (left > 64) pair_seg_group<1, 2, 2, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
-    else pair_seg_group<1, 2, 1, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    if (left > 64) pair_seg_group<1, PH_PAIR_U1, 2, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    else pair_seg_group<1, PH_PAIR_U1, 1, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
   }
   return part[0];
 }
@@ -347,106 +350,65 @@ __device__ __forceinline__ f2 pair_partial_small(const f2* __restrict__ xs, int 
   return (lane < p) ? tot * tot * w : f2_zero();
 }
 
-// All-reduce of a pair over the wavefront.  Inside a row of 16 lanes the DPP operand folds into the add
-// (v_add_f32_dpp: one instruction per float and level; ror 8, half mirror, xor 2, xor 1 -- no ds_swizzle, nothing goes
-// through the LDS pipe), then odd / even rows and half-waves are exchanged with v_permlane16_swap / v_permlane32_swap.
+// Wavefront totals of the per-lane pairs, PACKED: the consumers of a screen store the totals or test them in one lane,
+// nobody needs them in all 64.  v_permlane32_swap puts the two windows of a period side by side in one register (lanes
+// 0-31 window a, 32-63 window b: half the data per level from there on), v_permlane16_swap does the same with two
+// periods (rows of 16 lanes), and the rest of the tree runs inside the rows with the DPP operand folded into the add
+// (ror 8, half mirror, xor 2, xor 1 -- nothing goes through the LDS pipe).  9 instructions for one period, 10 for two
+// (the all-lanes versions of round 3: 20 and 22).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
-__device__ __forceinline__ f2 pair_wave_sum(f2 v) {
-  float x = v.x, y = v.y;
-  x += dpp_f32<kDppRor8>(x);
-  y += dpp_f32<kDppRor8>(y);
-  x += dpp_f32<kDppHalfMirror>(x);
-  y += dpp_f32<kDppHalfMirror>(y);
-  x += dpp_f32<kDppXor2>(x);
-  y += dpp_f32<kDppXor2>(y);
-  x += dpp_f32<kDppXor1>(x);
-  y += dpp_f32<kDppXor1>(y);
-  {
-    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
-    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-    x = __int_as_float((int)r0[0]) + __int_as_float((int)r0[1]);
-    y = __int_as_float((int)r1[0]) + __int_as_float((int)r1[1]);
-  }
-  {
-    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
-    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-    x = __int_as_float((int)r0[0]) + __int_as_float((int)r0[1]);
-    y = __int_as_float((int)r1[0]) + __int_as_float((int)r1[1]);
-  }
-  return f2_make(x, y);
-}
-
-// Two values at once: afterwards lanes 0-31 hold the wavefront total of `a`, lanes 32-63 that of `b` -- one
-// v_permlane32_swap pairing replaces the half-wave level of two separate reductions (18 instead of 36 instructions for
-// the two periods of a two-class pass).
 template <bool MX>
-__device__ __forceinline__ f2 pair_wave_red2(f2 a, f2 b) {
+__device__ __forceinline__ float pair_row_reduce(float z) {
   auto op = [](float u, float v) { return MX ? fmaxf(u, v) : u + v; };
-  float x, y;
-  {
-    unsigned l0 = (unsigned)__float_as_int(a.x), l1 = (unsigned)__float_as_int(a.y);
-    unsigned h0 = (unsigned)__float_as_int(b.x), h1 = (unsigned)__float_as_int(b.y);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);
-    x = op(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
-    y = op(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
-  }
-  x = op(x, dpp_f32<kDppRor8>(x));
-  y = op(y, dpp_f32<kDppRor8>(y));
-  x = op(x, dpp_f32<kDppHalfMirror>(x));
-  y = op(y, dpp_f32<kDppHalfMirror>(y));
-  x = op(x, dpp_f32<kDppXor2>(x));
-  y = op(y, dpp_f32<kDppXor2>(y));
-  x = op(x, dpp_f32<kDppXor1>(x));
-  y = op(y, dpp_f32<kDppXor1>(y));
-  {
-    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
-    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-    x = op(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
-    y = op(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
-  }
-  return f2_make(x, y);
+  z = op(z, dpp_f32<kDppRor8>(z));
+  z = op(z, dpp_f32<kDppHalfMirror>(z));
+  z = op(z, dpp_f32<kDppXor2>(z));
+  z = op(z, dpp_f32<kDppXor1>(z));
+  return z;
 }
 
-__device__ __forceinline__ f2 pair_wave_max(f2 v) {  // non-negative values (squares)
-  float x = v.x, y = v.y;
-  x = fmaxf(x, dpp_f32<kDppRor8>(x));
-  y = fmaxf(y, dpp_f32<kDppRor8>(y));
-  x = fmaxf(x, dpp_f32<kDppHalfMirror>(x));
-  y = fmaxf(y, dpp_f32<kDppHalfMirror>(y));
-  x = fmaxf(x, dpp_f32<kDppXor2>(x));
-  y = fmaxf(y, dpp_f32<kDppXor2>(y));
-  x = fmaxf(x, dpp_f32<kDppXor1>(x));
-  y = fmaxf(y, dpp_f32<kDppXor1>(y));
-  {
-    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
-    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-    x = fmaxf(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
-    y = fmaxf(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
-  }
-  {
-    unsigned a0 = (unsigned)__float_as_int(x), a1 = (unsigned)__float_as_int(y), b0 = a0, b1 = a1;
-    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-    x = fmaxf(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));
-    y = fmaxf(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));
-  }
-  return f2_make(x, y);
+// one period: afterwards lanes 0-31 hold the wavefront total (MX: maximum) of v.x, lanes 32-63 that of v.y
+template <bool MX>
+__device__ __forceinline__ float pair_reduce1(f2 v) {
+  auto op = [](float u, float w) { return MX ? fmaxf(u, w) : u + w; };
+  const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(v.x), (unsigned)__float_as_int(v.y), false, false);
+  const float z = op(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));  // rows: x, x, y, y (two partials each)
+  const unsigned zi = (unsigned)__float_as_int(z);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(zi, zi, false, false);
+  return pair_row_reduce<MX>(op(__int_as_float((int)r1[0]), __int_as_float((int)r1[1])));
+}
+
+// two periods: afterwards the rows of 16 lanes hold the totals of a.x, a.y, b.x, b.y (lanes 0-15, 16-31, 32-47, 48-63)
+template <bool MX>
+__device__ __forceinline__ float pair_reduce2(f2 a, f2 b) {
+  auto op = [](float u, float w) { return MX ? fmaxf(u, w) : u + w; };
+  const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(a.x), (unsigned)__float_as_int(b.x), false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(a.y), (unsigned)__float_as_int(b.y), false, false);
+  const float x = op(__int_as_float((int)r0[0]), __int_as_float((int)r0[1]));  // rows: a.x, a.x, b.x, b.x
+  const float y = op(__int_as_float((int)r1[0]), __int_as_float((int)r1[1]));  // rows: a.y, a.y, b.y, b.y
+  const auto r2 = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(x), (unsigned)__float_as_int(y), false, false);
+  return pair_row_reduce<MX>(op(__int_as_float((int)r2[0]), __int_as_float((int)r2[1])));  // rows: a.x, a.y, b.x, b.y
+}
+
+// where the packed totals go in an array of pairs `vals` (entry q - q0 = {window a, window b} of period q)
+__device__ __forceinline__ void pair_store1(f2* vals, float z, int q, int q0) {
+  const int l = pair_lane();
+  if ((l & 31) == 0) reinterpret_cast<float*>(vals)[2 * (q - q0) + (l >> 5)] = z;
+}
+__device__ __forceinline__ void pair_store2(f2* vals, float z, int qa, int qb, int q0) {
+  const int l = pair_lane();
+  if ((l & 15) == 0) reinterpret_cast<float*>(vals)[2 * ((l < 32 ? qa : qb) - q0) + ((l >> 4) & 1)] = z;
 }
 
 // ---------------------------------------------------------------- chains of periods up to 64
 // The row-split pass at L <= 64 (lane l < L adds x[l + n L]: the fold to period L, contiguous reads) is the fold of
 // every divisor of L as well: S_{L/2}[l] = S_L[l] + S_L[l + L/2], and so on down the powers of two.  One pass of
 // N / L loads yields L, L/2, ..., L / 2^(nlev-1) -- the host plans 32 chains for the 63 periods up to 64 (PassPlan
-// m = 8 + nlev).  Two levels share one wavefront reduction (pair_wave_red2).  Any summation order is covered by
+// m = 8 + nlev).  Two levels share one wavefront reduction (pair_reduce2).  Any summation order is covered by
 // pair_radius.
 __device__ __forceinline__ f2 pair_shift_down(f2 v, int lane, int by) {  // v of lane + by (lanes that matter: < 64 - by)
   const int addr = ((lane + by) & (kWave - 1)) << 2;
@@ -494,29 +456,28 @@ __device__ __forceinline__ void pair_chain_small(const f2* __restrict__ xs, int 
       const PGeomF g2 = geom[q2];
       tot += pair_shift_down(tot, lane, q2);
       const f2 vb = pair_chain_term<MX>(tot, lane, q2, g2);
-      consume2(pair_wave_red2<MX>(va, vb), q, q2);
+      consume2(pair_reduce2<MX>(va, vb), q, q2);
       if (lev + 2 < nlev) {
         q = q2 >> 1;
         g = geom[q];
         tot += pair_shift_down(tot, lane, q);
       }
     } else {
-      consume(MX ? pair_wave_max(va) : pair_wave_sum(va), q);
+      consume(pair_reduce1<MX>(va), q);
     }
   }
 }
 
-// Screen sweep driven by the pass plan: consume({ss_a, ss_b}, q) runs in every lane with the wavefront's totals;
-// consume2(v, q_a, q_b) delivers two periods of a multi-class pass (or two levels of a chain) at once, lanes 0-31
-// holding the totals of q_a and lanes 32-63 those of q_b.
-// Every period is reduced over the wavefront on its own (pair_wave_sum): a few more VALU per period than the online
-// 8-period butterfly of the fp64 sweeps, but nothing is live across the folds -- the butterfly's pending partials
-// were spilled and reloaded in every pass (3.03 -> 2.82 ms for k_mbest_step1_pair at config 2).
+// Screen sweep driven by the pass plan.  consume(z, q) gets the packed totals of one period (pair_reduce1: lanes 0-31
+// window a, 32-63 window b), consume2(z, q_a, q_b) those of two periods of a multi-class pass or two levels of a chain
+// (pair_reduce2: rows of 16 lanes = q_a window a, q_a window b, q_b window a, q_b window b); pair_store1 / pair_store2
+// put them into an array.  Every period is reduced on its own: nothing is live across the folds (the online 8-period
+// butterfly of the fp64 sweeps kept pending partials that were spilled in every pass: 3.03 -> 2.82 ms in round 3).
 template <bool MX = false, typename F, typename F2>
 __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N, const PGeomF* __restrict__ geom,
                                                 const PassPlan* __restrict__ plan, int i_first, int i_end, int stride,
                                                 F&& consume, F2&& consume2, int* __restrict__ queue = nullptr) {
-  auto red = [](f2 v) { return MX ? pair_wave_max(v) : pair_wave_sum(v); };
+  auto red = [](f2 v) { return pair_reduce1<MX>(v); };
   // `queue` (an LDS counter the caller has set to `stride`, the number of wavefronts): the passes are taken in plan
   // order by whichever wavefront is free -- the passes differ in cost and the sweep ends at a barrier.
   for (int i = i_first; i < i_end;) {
@@ -532,11 +493,11 @@ __device__ __forceinline__ void pair_sweep_plan(const f2* __restrict__ xs, int N
     } else if (m == 2) {
       f2 part[3];
       pair_pass_multi<2, MX>(xs, p, geom, part);
-      consume2(pair_wave_red2<MX>(part[0], part[1]), p, 2 * p);
+      consume2(pair_reduce2<MX>(part[0], part[1]), p, 2 * p);
     } else {
       f2 part[3];
       pair_pass_multi<4, MX>(xs, p, geom, part);
-      consume2(pair_wave_red2<MX>(part[0], part[1]), p, 2 * p);
+      consume2(pair_reduce2<MX>(part[0], part[1]), p, 2 * p);
       consume(red(part[2]), 4 * p);
     }
     i = queue ? lds_ticket_value(ticket) : i + stride;

@@ -282,13 +282,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         if (pair_lane() == 0) nxt = lds_ticket(&qc[S2L_TICK]);  // the next ticket: claimed now, looked at after this pass
         const float kap = kapf[q];
         const PGeomF gq = geomf[q];
-        const f2 v = pair_wave_sum(q >= 64 ? pair_pass_single(pw, q, gq) : pair_partial_small(pw, N, q, gq));
-        const bool f0 = q >= pos0 && !(v.x <= fmaf(-t01, kap, t00));  // NaN -> evaluate
-        const bool f1 = q >= pos1 && !(v.y <= fmaf(-t11, kap, t10));
-        if ((f0 || f1) && pair_lane() == 0) {
-          if (f0) atomicMin(&qc[S2L_STOP0], q);
-          if (f1) atomicMin(&qc[S2L_STOP1], q);
-          atomicMin(&qc[S2L_LIMIT], q);
+        // packed totals: lanes 0-31 hold the value of window 0, lanes 32-63 that of window 1 -- each half tests its own
+        const float z = pair_reduce1<false>(q >= 64 ? pair_pass_single(pw, q, gq) : pair_partial_small(pw, N, q, gq));
+        {
+          const int l = pair_lane();
+          const bool second = l >= 32;
+          const float bound = second ? fmaf(-t11, kap, t10) : fmaf(-t01, kap, t00);
+          const bool flag = q >= (second ? pos1 : pos0) && !(z <= bound);  // NaN -> evaluate
+          if (flag && (l & 31) == 0) {
+            atomicMin(&qc[second ? S2L_STOP1 : S2L_STOP0], q);
+            atomicMin(&qc[S2L_LIMIT], q);
+          }
         }
         q = lds_ticket_value(nxt);
 #ifdef PH_S2L_EXTRA_SALU  // sensitivity probe: PH_S2L_EXTRA_SALU x 8 scalar adds (or vector adds with PH_S2L_EXTRA_VALU) per pass

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cmath>
 
 using namespace ph;
 
@@ -25,18 +26,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform, as the pass queues of the kernels deliver it
   for (int r = 0; r < reps; ++r) {
     for (int q = q_lo + wave; q < q_hi; q += 8) {
-      f2 tot;
+      f2* vals = reinterpret_cast<f2*>(out);
+      const bool keep = blockIdx.x == 0 && r == 0;
       if (V == 1) {
-        tot = pair_wave_sum(pair_pass_single<false>(xs, q, geom[q]));
+        const float z = pair_reduce1<false>(pair_pass_single<false>(xs, q, geom[q]));
+        if (keep) pair_store1(vals, z, q, 0);
       } else {
         f2 part[3];
         pair_pass_multi<(V == 1 ? 2 : V), false>(xs, q, geom, part);
-        tot = pair_wave_red2<false>(part[0], part[1]);
-        if (V == 4) tot += pair_wave_sum(part[2]);
-      }
-      if (blockIdx.x == 0 && r == 0 && pair_lane() == 0) {
-        out[2 * q] = tot.x;
-        out[2 * q + 1] = tot.y;
+        const float z = pair_reduce2<false>(part[0], part[1]);
+        if (keep) pair_store2(vals, z, q, 2 * q, 0);
+        if (V == 4) {
+          const float z4 = pair_reduce1<false>(part[2]);
+          if (keep) pair_store1(vals, z4, 4 * q, 0);
+        }
       }
     }
   }
@@ -75,6 +78,36 @@ int main(int argc, char** argv) {
     best = ms < best ? ms : best;
   }
   const double passes = (double)blocks * reps * (q_hi - q_lo);
+  {  // the stored totals of block 0 against a double-precision fold of its window on the host
+    std::vector<float> h(2 * (N + 1));
+    hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
+    std::vector<double> xa(N), xb(N);
+    for (int i = 0; i < N; ++i) {
+      const float va = sinf(0.37f * i) + 0.25f * cosf(1.1f * i);
+      xa[i] = va;
+      xb[i] = 0.5f * va + 0.125f;
+    }
+    double worst = 0;
+    int at = 0, checked = 0;
+    for (int q = q_lo; q < q_hi; ++q)
+      for (int m = 1; m <= v; m *= 2) {
+        const int Q = m * q;
+        for (int w = 0; w < 2; ++w) {
+          const std::vector<double>& x = w ? xb : xa;
+          double ss = 0;
+          for (int j = 0; j < Q; ++j) {
+            double sj = 0;
+            int cnt = 0;
+            for (int i = j; i < N; i += Q) sj += x[i], cnt += 1;
+            if (cnt) ss += sj * sj / cnt;
+          }
+          const double d = fabs(ss - (double)h[2 * Q + w]) / fmax(1e-30, ss);
+          if (d > worst) worst = d, at = Q;
+          checked += 1;
+        }
+      }
+    printf("values of block 0 against the host fold: largest relative difference %.3g (period %d, %d values)\n", worst, at, checked);
+  }
   printf("%d-class pass: %.3f ms for %.0f passes (q in [%d, %d)): %.1f ns per pass per CU\n", v, best, passes, q_lo, q_hi,
          best * 1e6 / (passes / 256.0));
   return 0;
