@@ -39,20 +39,17 @@ struct Tables {
 // ---------------------------------------------------------------- LDS tickets
 typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
 
-// ds_add_rtn_u32 by the calling lane: `atomicAdd` on LDS goes through the compiler's atomic optimiser, which wraps the one
-// active lane's add into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane, v_add)
+// The next value of an LDS counter for the calling lane.  `atomicAdd` by one lane goes through the compiler's atomic
+// optimiser, which wraps it into a wave-wide aggregation (two v_mbcnt, s_bcnt1, a second exec mask, readfirstlane,
+// v_add); ds_inc_rtn_u32 with the wrap-around bound at 2^32 - 1 is the same increment, is not touched by that pass, and
+// -- unlike inline assembly -- stays known to the compiler as an outstanding LDS operation (it places the wait in front
+// of the first use of the result, wherever the register allocator moves it).  Claim a ticket before a pass and look at
+// it after the pass: the wait is free by then.
 __device__ __forceinline__ int lds_ticket(int* counter) {
-  int old;
-  const __attribute__((address_space(3))) int* p = (const __attribute__((address_space(3))) int*)counter;
-  const int one = 1;
-  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(p), "v"(one) : "memory");
-  return old;  // NOT waited for: the compiler does not count the asm's LDS operation -- read it with lds_ticket_value
+  return (int)__builtin_amdgcn_atomic_inc32((unsigned*)counter, 0xffffffffu, __ATOMIC_RELAXED, "workgroup");
 }
-// the ticket of lane 0 as a wave-uniform value (claim early, look at it after the pass: the wait is free by then)
-__device__ __forceinline__ int lds_ticket_value(int t) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t));
-  return __builtin_amdgcn_readfirstlane(t);
-}
+// the ticket of lane 0 as a wave-uniform value
+__device__ __forceinline__ int lds_ticket_value(int t) { return __builtin_amdgcn_readfirstlane(t); }
 
 // ---------------------------------------------------------------- wavefront / block reductions
 // Cross-lane moves for doubles on gfx950 without ds_bpermute (which costs LDS cycles and a per-lane address
