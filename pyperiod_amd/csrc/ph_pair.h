@@ -61,8 +61,12 @@ __device__ __forceinline__ int pair_lane() {
 }
 
 // ---------------------------------------------------------------- few-row single passes (R <= 6)
-template <int NR, int C, bool MASK, bool MX>
-__device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int lane, f2& part) {
+// STR (with MASK): the last chunk STRADDLES the cut of the period -- its lanes below `nvalid` are residues with NR
+// samples, the lanes from there up to `nvalid2` residues with NR - 1 whose last-row load falls into the zeroed pad
+// behind the window (index (NR-1) p + j >= N exactly for those j, and < N + 64): one chunk serves both count classes,
+// and the part with the short residues starts on a chunk boundary.  Their squares go to `part2`.
+template <int NR, int C, bool MASK, bool MX, bool STR = false>
+__device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int nvalid2, int lane, f2& part, f2& part2) {
   f2 v[NR][C];
 #pragma unroll
   for (int r = 0; r < NR; ++r)
@@ -75,15 +79,28 @@ __device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid,
     f2 t = v[0][c];
 #pragma unroll
     for (int r = 1; r < NR; ++r) t += v[r][c];
-    if (MASK && c == C - 1) t = (64 * c + lane < nvalid) ? t : f2_zero();  // a masked group is cut in its LAST chunk only
+    if (MASK && c == C - 1) {  // a masked group is cut in its LAST chunk only
+      const int col = 64 * c + lane;
+      if (STR) {
+        const f2 t2 = (col >= nvalid && col < nvalid2) ? t : f2_zero();
+        part2 = f2_acc<MX>(part2, t2);
+      }
+      t = (col < nvalid) ? t : f2_zero();
+    }
     part = f2_acc<MX>(part, t);
   }
 }
+template <int NR, int C, bool MASK, bool MX>
+__device__ __forceinline__ void pair_rows_group(pair_ptr ptr, int p, int nvalid, int lane, f2& part) {
+  pair_rows_group<NR, C, MASK, MX, false>(ptr, p, nvalid, nvalid, lane, part, part);
+}
 
 // ---------------------------------------------------------------- general segmented group (see seg_group)
-template <int M, int U, int C, bool MASK, bool MX>
-__device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, int nvalid, int lane,
-                                               const float (&wgt)[7], f2 (&part)[3]) {
+// STR: as in pair_rows_group -- the lanes of the last chunk from `nvalid` up to `nvalid2` are residues with one sample
+// fewer (their last row reads the zeroed pad); their squares take the weights `wgt2` and go to `part2`.
+template <int M, int U, int C, bool MASK, bool MX, bool STR = false>
+__device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, int nvalid, int nvalid2, int lane,
+                                               const float (&wgt)[7], const float (&wgt2)[7], f2 (&part)[3], f2 (&part2)[3]) {
   static_assert(U % M == 0, "a row block must cover whole class cycles");
   f2 a[M][C];
   int r = 0;
@@ -140,47 +157,66 @@ __device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, i
       }
     }
   }
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    // a masked group holds exactly the chunks that are left: only the last one is cut -- one class by zeroing its sum,
-    // several classes by running their squares under the lane mask (two scalar instructions instead of 2 M selects)
-    if (MASK && c == C - 1 && M == 1) a[0][c] = (64 * c + lane < nvalid) ? a[0][c] : f2_zero();
-    if (MASK && c == C - 1 && M > 1 && !(64 * c + lane < nvalid)) continue;
+  // squares of the class sums of chunk c into `pt` with the weights `w`
+  auto fin = [&](int c, const float (&w)[7], f2 (&pt)[3]) {
     if (M == 1) {
-      part[0] = f2_acc<MX>(part[0], a[0][c]);
+      pt[0] = f2_acc<MX>(pt[0], a[0][c]);
     } else if (MX) {  // max |S| of p, 2p and (M == 4) 4p from the class sums; no count weights
       const f2 e = M == 4 ? a[0][c] + a[2 % M][c] : a[0][c], o = M == 4 ? a[1 % M][c] + a[3 % M][c] : a[1 % M][c];
-      part[0] = f2_acc<true>(part[0], e + o);
-      part[1] = f2_acc<true>(f2_acc<true>(part[1], e), o);
+      pt[0] = f2_acc<true>(pt[0], e + o);
+      pt[1] = f2_acc<true>(f2_acc<true>(pt[1], e), o);
       if (M == 4) {
 #pragma unroll
-        for (int u = 0; u < M; ++u) part[2] = f2_acc<true>(part[2], a[u][c]);
+        for (int u = 0; u < M; ++u) pt[2] = f2_acc<true>(pt[2], a[u][c]);
       }
     } else if (M == 2) {
       const f2 e = a[0][c], o = a[1 % M][c], t = e + o;
-      part[0] = f2_fma(t, t, part[0]);
-      part[1] = f2_fma(e, e, part[1]);
-      part[2] = f2_fma(o, o, part[2]);
+      pt[0] = f2_fma(t, t, pt[0]);
+      pt[1] = f2_fma(e, e, pt[1]);
+      pt[2] = f2_fma(o, o, pt[2]);
     } else {
       const f2 e = a[0][c] + a[2 % M][c], o = a[1 % M][c] + a[3 % M][c], t = e + o;
-      part[0] = f2_fma(t, t * wgt[0], part[0]);
-      part[1] = f2_fma(e, e * wgt[1], part[1]);
-      part[1] = f2_fma(o, o * wgt[2], part[1]);
+      pt[0] = f2_fma(t, t * w[0], pt[0]);
+      pt[1] = f2_fma(e, e * w[1], pt[1]);
+      pt[1] = f2_fma(o, o * w[2], pt[1]);
 #pragma unroll
-      for (int u = 0; u < M; ++u) part[2] = f2_fma(a[u][c], a[u][c] * wgt[3 + u], part[2]);
+      for (int u = 0; u < M; ++u) pt[2] = f2_fma(a[u][c], a[u][c] * w[3 + u], pt[2]);
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    if (MASK && c == C - 1) {
+      // a masked group holds exactly the chunks that are left: only the last one is cut -- one class without a straddle
+      // by zeroing its sum, otherwise by running the squares under the lane masks (two scalar instructions, no selects)
+      const int col = 64 * c + lane;
+      if (M == 1) {  // (selects, not branches: the compiler turns the choice between the two arrays into a scratch pointer)
+        part[0] = f2_acc<MX>(part[0], (col < nvalid) ? a[0][c] : f2_zero());
+        if (STR) part2[0] = f2_acc<MX>(part2[0], (col >= nvalid && col < nvalid2) ? a[0][c] : f2_zero());
+      } else if (col < nvalid) {
+        fin(c, wgt, part);
+      } else if (STR && col < nvalid2) {
+        fin(c, wgt2, part2);
+      }
+    } else {
+      fin(c, wgt, part);
     }
   }
 }
+template <int M, int U, int C, bool MASK, bool MX>
+__device__ __forceinline__ void pair_seg_group(pair_ptr ptr, int p, int nrows, int nvalid, int lane,
+                                               const float (&wgt)[7], f2 (&part)[3]) {
+  pair_seg_group<M, U, C, MASK, MX, false>(ptr, p, nrows, nvalid, nvalid, lane, wgt, wgt, part, part);
+}
 
-// ---------------------------------------------------------------- single-period pass with one dispatch
 // Per-lane partials of sum_j S_q[j]^2 / cnt_q[j] of BOTH windows, base period p >= 64; segment logic of seg_group.
 // The pass is dispatched once, on the row count of the period, to straight-line code for both segments (see "passes
 // with one dispatch" in ph_device.h: one CU has one scalar unit, and the screens kept it ~90 % busy; measured with
 // tools/micro/pair_pass_bench.hip: 129 -> 71 scalar instructions per few-row pass, 100 -> 85 ns per pass and CU).
-template <int NR, bool MX>
-__device__ __forceinline__ f2 pair_single_rows(pair_ptr base, int p, int len, int lane) {
+// columns [0, len) from `base` (lane included), NR samples each; STR: `len` is the cut of the period, and the chunk
+// that holds it also takes the residues behind it (up to column `cols`) into `part2`
+template <int NR, bool MX, bool STR = false>
+__device__ __forceinline__ void pair_single_rows(pair_ptr base, int p, int len, int cols, int lane, f2& part, f2& part2) {
   constexpr int CG = NR <= 4 ? 4 : 2;
-  f2 part = f2_zero();
   const int whole = len >> 6;
   int c = 0;
   for (; c + CG <= whole; c += CG) pair_rows_group<NR, CG, false, MX>(base + 64 * c, p, 0, lane, part);
@@ -191,76 +227,76 @@ __device__ __forceinline__ f2 pair_single_rows(pair_ptr base, int p, int len, in
   const int rem = len & 63;
   if (rem) {
     asm volatile("" ::: "memory");
-    pair_rows_group<NR, 1, true, MX>(base + 64 * whole, p, rem, lane, part);
+    pair_rows_group<NR, 1, true, MX, STR>(base + 64 * whole, p, rem, cols - 64 * whole, lane, part, part2);
   }
-  return part;
 }
 
 #ifndef PH_PAIR_U1
 #define PH_PAIR_U1 2  // rows per load block of the many-row single passes
 #endif
-template <bool MX>
-__device__ __forceinline__ f2 pair_single_general(pair_ptr base, int p, int len, int nrows, int lane) {
-  f2 part[3] = {f2_zero(), f2_zero(), f2_zero()};
-  const float wgt[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+// one part of a pass: columns [0, len) from `base` (lane included), nrows samples each, squares into `part` with the
+// weights `wgt`.  STR: `len` is the cut of the period; the chunk that holds it also takes the residues behind it, up to
+// column `cols`, with the weights `wgt2` into `part2`.
+template <int M, int U, bool MX, bool STR = false>
+__device__ __forceinline__ void pair_multi_segment(pair_ptr base, int p, int len, int cols, int nrows, int lane,
+                                                   const float (&wgt)[7], const float (&wgt2)[7], f2 (&part)[3], f2 (&part2)[3]) {
+  constexpr int CM = (M == 4) ? 2 : 4;
   const int whole = len >> 6;
   int c = 0;
-  for (; c + 4 <= whole; c += 4) pair_seg_group<1, PH_PAIR_U1, 4, false, MX>(base + 64 * c, p, nrows, 256, lane, wgt, part);
-  const int left = len - 64 * c;  // < 256 columns
-  if (left > 128) {
-    if (left > 192) pair_seg_group<1, PH_PAIR_U1, 4, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
-    else pair_seg_group<1, PH_PAIR_U1, 3, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+  for (; c + CM <= whole; c += CM) pair_seg_group<M, U, CM, false, MX>(base + 64 * c, p, nrows, 64 * CM, lane, wgt, part);
+  const int left = len - 64 * c;  // < 64 CM columns
+  const int left2 = cols - 64 * c;
+  const pair_ptr at = base + 64 * c;
+  if (CM == 4 && left > 128) {
+    if (left > 192) pair_seg_group<M, U, (CM == 4 ? 4 : 1), true, MX, STR>(at, p, nrows, left, left2, lane, wgt, wgt2, part, part2);
+    else pair_seg_group<M, U, (CM == 4 ? 3 : 1), true, MX, STR>(at, p, nrows, left, left2, lane, wgt, wgt2, part, part2);
+  } else if (left > 64) {
+    pair_seg_group<M, U, 2, true, MX, STR>(at, p, nrows, left, left2, lane, wgt, wgt2, part, part2);
   } else if (left > 0) {
-    if (left > 64) pair_seg_group<1, PH_PAIR_U1, 2, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
-    else pair_seg_group<1, PH_PAIR_U1, 1, true, MX>(base + 64 * c, p, nrows, left, lane, wgt, part);
+    pair_seg_group<M, U, 1, true, MX, STR>(at, p, nrows, left, left2, lane, wgt, wgt2, part, part2);
   }
-  return part[0];
 }
 
-// Per-lane partials of sum_j S_p[j]^2 / cnt_p[j] (MX: max_j S_p[j]^2) of both windows, p >= 64
+// Per-lane partials of sum_j S_p[j]^2 / cnt_p[j] (MX: max_j S_p[j]^2) of both windows, p >= 64.  The residues below
+// the cut c = nfull own `rows` samples, the others one fewer; part A is every chunk up to and including the one that
+// holds c - 1 (its lanes behind the cut ride along: STR), part B starts on the next chunk boundary -- ceil(p / 64)
+// chunk columns per pass instead of ceil(c / 64) + ceil((p - c) / 64).
 template <bool MX = false>
 __device__ __forceinline__ f2 pair_pass_single(const f2* __restrict__ xs, int p, const PGeomF g) {
   const int lane = pair_lane();
-  const pair_ptr a = (pair_ptr)xs + lane, b = a + g.nfull;
-  const int cut = g.nfull, rest = p - cut;
-  f2 sa, sb;
+  const int cut = g.nfull;
+  const int acols = min(p, (cut + 63) & ~63), rest = p - acols;
+  const pair_ptr a = (pair_ptr)xs + lane, b = a + acols;
+  f2 sa = f2_zero(), sb = f2_zero();
   switch (g.rows) {
-    case 2: sa = pair_single_rows<2, MX>(a, p, cut, lane); sb = pair_single_rows<1, MX>(b, p, rest, lane); break;
-    case 3: sa = pair_single_rows<3, MX>(a, p, cut, lane); sb = pair_single_rows<2, MX>(b, p, rest, lane); break;
-    case 4: sa = pair_single_rows<4, MX>(a, p, cut, lane); sb = pair_single_rows<3, MX>(b, p, rest, lane); break;
-    case 5: sa = pair_single_rows<5, MX>(a, p, cut, lane); sb = pair_single_rows<4, MX>(b, p, rest, lane); break;
-    case 6: sa = pair_single_rows<6, MX>(a, p, cut, lane); sb = pair_single_rows<5, MX>(b, p, rest, lane); break;
-    default:
-      sa = pair_single_general<MX>(a, p, cut, g.rows, lane);
-      sb = pair_single_general<MX>(b, p, rest, g.rows - 1, lane);
+#define PH_SINGLE_CASE(R)                                              \
+  case R:                                                              \
+    pair_single_rows<R, MX, true>(a, p, cut, acols, lane, sa, sb);     \
+    pair_single_rows<R - 1, MX>(b, p, rest, rest, lane, sb, sb);       \
+    break;
+    PH_SINGLE_CASE(2)
+    PH_SINGLE_CASE(3)
+    PH_SINGLE_CASE(4)
+    PH_SINGLE_CASE(5)
+    PH_SINGLE_CASE(6)
+#undef PH_SINGLE_CASE
+    default: {
+      const float wgt[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      f2 pa[3] = {f2_zero(), f2_zero(), f2_zero()}, pb[3] = {f2_zero(), f2_zero(), f2_zero()};
+      pair_multi_segment<1, PH_PAIR_U1, MX, true>(a, p, cut, acols, g.rows, lane, wgt, wgt, pa, pb);
+      if (rest > 0) pair_multi_segment<1, PH_PAIR_U1, MX>(b, p, rest, rest, g.rows - 1, lane, wgt, wgt, pb, pb);
+      sa = pa[0];
+      sb = pb[0];
       break;
+    }
   }
   if (MX) return f2_max(sa, sb);
   return f2_fma(sa, f2_make(g.w_full, g.w_full), sb * g.w_short);
 }
 
 // ---------------------------------------------------------------- multi-class pass, straight-line segments
-// Period p, 2p (and 4p) from the class sums of one fold: the weights of a segment are compile-time indexed and chosen on
-// the scalar unit, the tail of a segment is picked by two compares, and no flag survives a branch.
-template <int M, bool MX>
-__device__ __forceinline__ void pair_multi_segment(pair_ptr base, int p, int len, int nrows, int lane,
-                                                   const float (&wgt)[7], f2 (&part)[3]) {
-  constexpr int CM = (M == 4) ? 2 : 4;
-  const int whole = len >> 6;
-  int c = 0;
-  for (; c + CM <= whole; c += CM) pair_seg_group<M, M, CM, false, MX>(base + 64 * c, p, nrows, 64 * CM, lane, wgt, part);
-  const int left = len - 64 * c;  // < 64 CM columns
-  const pair_ptr at = base + 64 * c;
-  if (CM == 4 && left > 128) {
-    if (left > 192) pair_seg_group<M, M, (CM == 4 ? 4 : 1), true, MX>(at, p, nrows, left, lane, wgt, part);
-    else pair_seg_group<M, M, (CM == 4 ? 3 : 1), true, MX>(at, p, nrows, left, lane, wgt, part);
-  } else if (left > 64) {
-    pair_seg_group<M, M, 2, true, MX>(at, p, nrows, left, lane, wgt, part);
-  } else if (left > 0) {
-    pair_seg_group<M, M, 1, true, MX>(at, p, nrows, left, lane, wgt, part);
-  }
-}
-
+// Period p, 2p (and 4p) from the class sums of one fold: the weights of a part are compile-time indexed and chosen on
+// the scalar unit, the tail of a part is picked by two compares, and no flag survives a branch.
 // (x < y) ? a : b of wave-uniform values on the scalar unit (the compiler's version of a float select under a scalar
 // condition is two v_mov and a v_cndmask)
 __device__ __forceinline__ float scalar_select_lt(int x, int y, float a, float b) {
@@ -275,9 +311,11 @@ __device__ __forceinline__ void pair_pass_multi(const f2* __restrict__ xs, int p
   static_assert(M == 2 || M == 4, "two or four classes");
   const PGeomF g1 = geom[p], g2 = geom[2 * p], g4 = geom[(M == 4 ? 4 : 2) * p];
   const int lane = pair_lane();
-  const int cut = g1.nfull, rest = p - cut;
+  const int cut = g1.nfull;
+  const int acols = min(p, (cut + 63) & ~63), rest = p - acols;  // part A: the chunks up to the one that holds the cut
   const pair_ptr a = (pair_ptr)xs + lane;
-  // class u of period 2p / 4p at column j is the residue u p + j: a whole segment lies on one side of nfull(2p), nfull(4p)
+  // class u of period 2p / 4p at column j is the residue u p + j: the columns below the cut lie on one side of
+  // nfull(2p), nfull(4p), the columns behind it on one side as well (weights wa / wb)
   float wa[7], wb[7];
   wa[0] = g1.w_full;
   wb[0] = g1.w_short;
@@ -294,13 +332,13 @@ __device__ __forceinline__ void pair_pass_multi(const f2* __restrict__ xs, int p
   }
   if (M == 4) {  // the weights are applied per chunk, straight into the totals
     total[0] = total[1] = total[2] = f2_zero();
-    pair_multi_segment<M, MX>(a, p, cut, g1.rows, lane, wa, total);
-    if (rest > 0) pair_multi_segment<M, MX>(a + cut, p, rest, g1.rows - 1, lane, wb, total);
+    pair_multi_segment<M, M, MX, true>(a, p, cut, acols, g1.rows, lane, wa, wb, total, total);
+    if (rest > 0) pair_multi_segment<M, M, MX>(a + acols, p, rest, rest, g1.rows - 1, lane, wb, wb, total, total);
     return;
   }
   f2 sa[3] = {f2_zero(), f2_zero(), f2_zero()}, sb[3] = {f2_zero(), f2_zero(), f2_zero()};
-  pair_multi_segment<M, MX>(a, p, cut, g1.rows, lane, wa, sa);
-  if (rest > 0) pair_multi_segment<M, MX>(a + cut, p, rest, g1.rows - 1, lane, wb, sb);
+  pair_multi_segment<M, M, MX, true>(a, p, cut, acols, g1.rows, lane, wa, wb, sa, sb);
+  if (rest > 0) pair_multi_segment<M, M, MX>(a + acols, p, rest, rest, g1.rows - 1, lane, wb, wb, sb, sb);
   if (MX) {
     total[0] = f2_max(sa[0], sb[0]);
     total[1] = f2_max(sa[1], sb[1]);

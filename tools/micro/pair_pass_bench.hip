@@ -20,7 +20,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   f2* xs = (f2*)smem;
   for (int i = threadIdx.x; i < N + 64; i += blockDim.x) {
     const float v = i < N ? __sinf(0.37f * i + 0.001f * blockIdx.x) + 0.25f * __cosf(1.1f * i) : 0.0f;
-    xs[i] = f2_make(v, 0.5f * v + 0.125f);
+    xs[i] = i < N ? f2_make(v, 0.5f * v + 0.125f) : f2_zero();  // the pad behind the window is read (straddling chunks)
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform, as the pass queues of the kernels deliver it
