@@ -829,7 +829,7 @@ __device__ __forceinline__ double wave_pass_single(const T* __restrict__ xs, int
   typedef typename Win<T, LDS>::ptr lds_ptr;
   const lds_ptr a = Win<T, LDS>::cast(xs) + lane, b = a + g.nfull;
   const int cut = g.nfull, rest = p - cut;
-  double sa, sb;
+  double sa = 0.0, sb = 0.0;
   bool done = false;
   if (!MAXABS) {  // few rows: compile-time row count (norm passes only: the max|S| kernels spill)
     done = true;

@@ -6,7 +6,8 @@
 // one ds_read_b64 brings a sample of both windows, v_pk_add_f32 / v_pk_fma_f32 fold both, and every address,
 // mask, weight and cross-lane instruction of a pass is shared between them -- the instruction stream of one
 // fp64 pass now serves two windows.  Always 8-byte aligned, no shifted copies, same register footprint as the
-// fp64 fold (a float pair is as wide as a double).
+// fp64 fold (a float pair is as wide as a double).  The window is followed by kPad ZEROED pairs: the chunk that holds
+// the cut of a period reads the missing last sample of its short residues from there (pair_rows_group, STR).
 //
 // The float values only SCREEN the candidates of an m_best iteration (Periods.py:501-515): a rigorous radius
 // (pair_radius) bounds |screen - exact|, and the periods whose upper bound reaches the best lower bound are
