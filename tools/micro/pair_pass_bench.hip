@@ -1,7 +1,8 @@
 // Test bed for the screen passes of the window-pair kernels (ph_pair.h): every wavefront of a workgroup walks the
 // periods q_lo + wave, q_lo + wave + 8, ... < q_hi over one LDS window pair, as the screens of k_small_to_large_pair /
 // k_mbest_step1_pair do, at their occupancy (4 workgroups of 8 wavefronts per CU).  Variant 1 is pair_pass_single,
-// 2 / 4 are pair_pass_multi with two / four classes (period q, 2q[, 4q] from one fold).  Time from hipEvents;
+// 2 / 4 are pair_pass_multi with two / four classes (period q, 2q[, 4q] from one fold).  Every value is checked against
+// the fp64 fold of the same float samples in units of the rigorous radius of the screen (pair_radius).  Time from hipEvents;
 // instruction counts per pass with tools/micro/pair_pass_pmc.sh.  profiles/r4_study/pair_pass_bench.txt holds the
 // numbers of the round-3 passes (one loop over the two segments) next to these.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I../../pyperiod_amd/csrc pair_pass_bench.hip -o pair_pass_bench
@@ -14,14 +15,11 @@
 using namespace ph;
 
 template <int V>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k(const PGeomF* __restrict__ geom, int N, int q_lo,
-                                                                                   int q_hi, int reps, float* __restrict__ out) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k(const PGeomF* __restrict__ geom, const f2* __restrict__ win,
+                                                                                   int N, int q_lo, int q_hi, int reps, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f2* xs = (f2*)smem;
-  for (int i = threadIdx.x; i < N + 64; i += blockDim.x) {
-    const float v = i < N ? __sinf(0.37f * i + 0.001f * blockIdx.x) + 0.25f * __cosf(1.1f * i) : 0.0f;
-    xs[i] = i < N ? f2_make(v, 0.5f * v + 0.125f) : f2_zero();  // the pad behind the window is read (straddling chunks)
-  }
+  for (int i = threadIdx.x; i < N + 64; i += blockDim.x) xs[i] = i < N ? win[i] : f2_zero();  // the pad is read (straddling chunks)
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform, as the pass queues of the kernels deliver it
   for (int r = 0; r < reps; ++r) {
@@ -56,6 +54,16 @@ int main(int argc, char** argv) {
     const int rows = (N + p - 1) / p, shortn = rows * p - N;
     g[p] = PGeomF{rows, p - shortn, (float)(1.0 / rows), rows > 1 ? (float)(1.0 / (rows - 1)) : 0.0f};
   }
+  // the window pair of every workgroup: two sinusoids plus a ramp, values of order 1 (the kernels scale to RMS ~ 1)
+  std::vector<float> hw(2 * (size_t)N);
+  for (int i = 0; i < N; ++i) {
+    const float va = sinf(0.37f * i) + 0.25f * cosf(1.1f * i);
+    hw[2 * i] = va;
+    hw[2 * i + 1] = 0.5f * va + 0.125f + 1e-4f * (i % 97);
+  }
+  f2* dwin;
+  hipMalloc(&dwin, hw.size() * sizeof(float));
+  hipMemcpy(dwin, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice);
   PGeomF* dg;
   float* out;
   hipMalloc(&dg, g.size() * sizeof(PGeomF));
@@ -66,11 +74,11 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const size_t lds = (size_t)(N + 64) * sizeof(f2);
-  void (*fn)(const PGeomF*, int, int, int, int, float*) = v == 1 ? k<1> : v == 2 ? k<2> : k<4>;
+  void (*fn)(const PGeomF*, const f2*, int, int, int, int, float*) = v == 1 ? k<1> : v == 2 ? k<2> : k<4>;
   float best = 1e9;
   for (int r = 0; r < 3; ++r) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, 0, dg, N, q_lo, q_hi, reps, out);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, 0, dg, dwin, N, q_lo, q_hi, reps, out);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -78,35 +86,34 @@ int main(int argc, char** argv) {
     best = ms < best ? ms : best;
   }
   const double passes = (double)blocks * reps * (q_hi - q_lo);
-  {  // the stored totals of block 0 against a double-precision fold of its window on the host
+  {  // every stored total against the double-precision fold of the same float samples, in units of the rigorous radius
     std::vector<float> h(2 * (N + 1));
     hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
-    std::vector<double> xa(N), xb(N);
-    for (int i = 0; i < N; ++i) {
-      const float va = sinf(0.37f * i) + 0.25f * cosf(1.1f * i);
-      xa[i] = va;
-      xb[i] = 0.5f * va + 0.125f;
-    }
-    double worst = 0;
+    double ssq[2] = {0, 0};
+    for (int i = 0; i < N; ++i)
+      for (int w = 0; w < 2; ++w) ssq[w] += (double)hw[2 * i + w] * hw[2 * i + w];
+    double worst = 0, worst_rel = 0;
     int at = 0, checked = 0;
     for (int q = q_lo; q < q_hi; ++q)
       for (int m = 1; m <= v; m *= 2) {
-        const int Q = m * q;
+        const int Q = m * q, rows = (N + Q - 1) / Q;
+        const double radius = 1.5 * (2.0 * rows + (double)(Q >> 6) + 32.0) * 5.9604644775390625e-08;  // pair_radius(rows, Q)
         for (int w = 0; w < 2; ++w) {
-          const std::vector<double>& x = w ? xb : xa;
           double ss = 0;
           for (int j = 0; j < Q; ++j) {
             double sj = 0;
             int cnt = 0;
-            for (int i = j; i < N; i += Q) sj += x[i], cnt += 1;
+            for (int i = j; i < N; i += Q) sj += (double)hw[2 * i + w], cnt += 1;
             if (cnt) ss += sj * sj / cnt;
           }
-          const double d = fabs(ss - (double)h[2 * Q + w]) / fmax(1e-30, ss);
-          if (d > worst) worst = d, at = Q;
+          const double err = fabs(ss - (double)h[2 * Q + w]);
+          worst_rel = fmax(worst_rel, err / fmax(1e-30, ss));
+          if (err / (radius * ssq[w]) > worst) worst = err / (radius * ssq[w]), at = Q;
           checked += 1;
         }
       }
-    printf("values of block 0 against the host fold: largest relative difference %.3g (period %d, %d values)\n", worst, at, checked);
+    printf("%d screen values against the fp64 fold: largest |error| / (pair_radius x sum of squares) = %.3f (period %d; must be < 1), largest relative error %.2e\n",
+           checked, worst, at, worst_rel);
   }
   printf("%d-class pass: %.3f ms for %.0f passes (q in [%d, %d)): %.1f ns per pass per CU\n", v, best, passes, q_lo, q_hi,
          best * 1e6 / (passes / 256.0));
