@@ -21,4 +21,7 @@ echo "bench line done"
 timeout -k 10 400 python3 bench.py --gpus 2 --backend gloo --steps 5 --warmup 1 --c4-windows 16384 > "$O/bench_gpus2_gloo_rehearsal.json" 2> "$O/bench_gpus2.err" || tail -3 "$O/bench_gpus2.err"
 echo "rehearsal done"
 timeout -k 10 200 python3 tools/call_latency.py > "$O/call_latency.txt" 2>&1
+# the screen passes in isolation: time, instruction counts and the radius check (tools/micro/pair_pass_bench.hip)
+( cd tools/micro && hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I../../pyperiod_amd/csrc pair_pass_bench.hip -o pair_pass_bench 2> /dev/null ) && rm -f "$O/pair_pass_bench.txt" && bash tools/micro/pair_pass_pmc.sh "gpurun_out/$T/pair_pass_bench.txt" > /dev/null 2>&1
+echo "pass test bed done"
 cat "$O/table.md"
